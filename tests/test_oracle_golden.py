@@ -1,0 +1,131 @@
+"""Pin the CPU oracle (oracle/denoiser_oracle.py) against fixtures generated from
+the reference's own unmodified modules (oracle/make_golden.py) and the
+known-answer vectors of SURVEY.md App. D.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_oracle as O
+
+CASES = {
+    "tiny_inflated": dict(in_channels=64, num_layers=5, num_attention_heads=2, width=256,
+                          mlp_ratio=4.0, cross_attention_dim=64, inflated_layers=(0, 1, 2, 3, 4)),
+    "tiny_mixed": dict(in_channels=64, num_layers=5, num_attention_heads=2, width=256,
+                       mlp_ratio=4.0, cross_attention_dim=64, inflated_layers=(0, 1, 3, 4)),
+}
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_weights_regenerate_identically(golden_dir, name):
+    g = _load(golden_dir, name)
+    sd = O.synthetic_state_dict(O.OracleConfig(**CASES[name]), seed=0)
+    assert O.state_dict_checksum(sd) == pytest.approx(float(g["weights_checksum"]), rel=1e-12)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference_fp32(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = O.OracleConfig(**CASES[name])
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x = torch.from_numpy(g["init_latent"]); c = torch.from_numpy(g["context"])
+    m = torch.from_numpy(g["mask"]); f = torch.from_numpy(g["framestep"])
+    x_in, c_in, m_in, f_in = O.cfg_at_inference(x, c, m, f, [[0, 1], [1, 1]])
+    t = torch.tensor([float(g["fwd_t"])]).expand(2)
+    v = O.denoiser_forward(sd, cfg, x_in, c_in, f_in, t, m_in, "fp32")
+    ref = torch.from_numpy(g["fwd_velocity_fp32"])
+    # same fp32 arithmetic, different op grouping -> rounding-level agreement
+    assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5), float((v - ref).abs().max())
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loop_matches_reference_fp32(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = O.OracleConfig(**CASES[name])
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x = torch.from_numpy(g["init_latent"]); c = torch.from_numpy(g["context"])
+    m = torch.from_numpy(g["mask"]); f = torch.from_numpy(g["framestep"])
+    calls = []
+    lat = O.flow_sample(sd, cfg, x, c, m, f, int(g["steps"]), precision="fp32",
+                        step_callback=lambda i, n: calls.append((i, n)))
+    ref = torch.from_numpy(g["loop_latents_fp32"])
+    assert len(lat) == ref.shape[0] == int(g["steps"])
+    for i, l in enumerate(lat):
+        assert torch.allclose(l, ref[i], rtol=1e-4, atol=5e-5), (i, float((l - ref[i]).abs().max()))
+    # conditioning frame (mask == 1) is never overwritten (scheduler.py:244-248)
+    assert torch.equal(lat[-1][0, 0], x[0, 0])
+    assert calls == [(i + 1, int(g["steps"])) for i in range(int(g["steps"]))]
+    # split_cfg_batch=True run of the reference agrees with the batched run
+    assert torch.allclose(lat[-1], torch.from_numpy(g["loop_final_split_cfg_fp32"]), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_bf16_policy_is_close_to_fp32_and_to_cpu_autocast(golden_dir, name):
+    """The bf16-emulating policy must stay within bf16-level distance of the
+    fp32 reference, and be about as close to the reference run under CPU
+    autocast(bf16) as that run is to fp32."""
+    g = _load(golden_dir, name)
+    cfg = O.OracleConfig(**CASES[name])
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x = torch.from_numpy(g["init_latent"]); c = torch.from_numpy(g["context"])
+    m = torch.from_numpy(g["mask"]); f = torch.from_numpy(g["framestep"])
+    x_in, c_in, m_in, f_in = O.cfg_at_inference(x, c, m, f, [[0, 1], [1, 1]])
+    t = torch.tensor([float(g["fwd_t"])]).expand(2)
+    vb = O.denoiser_forward(sd, cfg, x_in, c_in, f_in, t, m_in, "bf16")
+    ref32 = torch.from_numpy(g["fwd_velocity_fp32"])
+    refac = torch.from_numpy(g["fwd_velocity_cpu_autocast_bf16"])
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(vb, ref32) < 2e-2
+    assert rel(refac, ref32) < 2e-2
+    assert rel(vb, refac) < 2e-2
+
+
+def test_uncond_cross_attention_is_bias(golden_dir):
+    """context == 0 and bias-free to_k/to_v => cross-attn output == to_out bias."""
+    cfg = O.OracleConfig(**CASES["tiny_inflated"])
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    z = torch.randn(3, 10, cfg.width)
+    o = O.cross_attention(z, torch.zeros(3, 5, cfg.cross_attention_dim), sd, "blocks.0.x_attn.",
+                          cfg.num_attention_heads, O.Precision("fp32"))
+    assert torch.allclose(o, sd["blocks.0.x_attn.to_out.0.bias"].expand_as(o), atol=1e-6)
+
+
+def test_kats(golden_dir):
+    k = _load(golden_dir, "kats")
+    for n in (10, 15, 30, 50):
+        t, d = O.get_schedule(n, shift=3.0)
+        assert np.array_equal(t.numpy(), k[f"sched_t_{n}"])
+        assert np.array_equal(d.numpy(), k[f"sched_d_{n}"])
+        assert t[-1].item() == pytest.approx(8.9285717, rel=1e-6)
+        assert d.sum().item() == pytest.approx(0.9910714, rel=1e-5)
+    # SURVEY App. D literal values
+    t10, d10 = O.get_schedule(10)
+    assert np.allclose(t10[:4].numpy(), [1000.0, 964.40027, 923.34253, 875.46747], rtol=1e-6)
+    assert np.allclose(d10[:3].numpy(), [0.03559973, 0.04105774, 0.04787506], rtol=1e-5)
+    cos, sin = O.rope_tables(torch.arange(16.0)[None], 128)
+    assert np.allclose(cos.numpy(), k["rope_cos_128_16"], atol=1e-6)
+    assert np.allclose(sin.numpy(), k["rope_sin_128_16"], atol=1e-6)
+    x = torch.from_numpy(k["rope_apply_in"])
+    y = O.apply_rope(x, cos[None].expand(1, 16, 128), sin[None].expand(1, 16, 128))
+    assert np.allclose(y.numpy(), k["rope_apply_out"], atol=1e-6)
+    assert float(torch.from_numpy(k["rope_apply_out"]).double().sum()) == pytest.approx(-59.52107881667325, abs=1e-4)
+    n = O.get_noise([8, 4], 1, 3, torch.Generator().manual_seed(7))
+    assert np.array_equal(n.numpy(), k["noise_seed7_small"])
+    n44 = O.get_noise([2048, 64], 1, 16, torch.Generator().manual_seed(44))
+    assert np.allclose(n44[0, :2, 0, :3].numpy(), k["noise_seed44_head"])
+    v = O.aggregate_cfg(torch.tensor([[1.0], [2.0]]), 2, [7.5], O.Precision("fp32"))
+    assert np.allclose(v.numpy(), k["cfg_aggregate_1_2"]) and float(v) == 8.5
+
+
+def test_step_flops_match_survey():
+    nominal = O.OracleConfig()
+    assert O.step_flops(2, 16, 2048, nominal, 257) == pytest.approx(5.4689e14, rel=2e-4)
+    head = O.OracleConfig(width=1024, num_attention_heads=8)
+    assert O.step_flops(2, 16, 4096, head, 257) == pytest.approx(8.2922e14, rel=2e-4)
+    assert O.step_flops(2, 64, 8192, head, 257) == pytest.approx(4.8016e16, rel=2e-4)

@@ -1,0 +1,124 @@
+"""ctypes binding of libactionmesh_amd.so (the C-ABI in include/actionmesh_amd.h).
+
+The HIP library is the product.  There is NO CPU fallback: importing this module
+never fails (so host-side logic stays testable without a GPU), but `lib()` raises
+`HipLibraryMissing` when the shared object has not been built, and every compute
+entry point raises `RuntimeError(am_last_error())` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libactionmesh_amd.so")
+ABI_VERSION = 1
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class AmConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("width", C.c_int32), ("ff_inner", C.c_int32), ("cross_dim", C.c_int32),
+        ("inflated_mask_lo", C.c_uint32), ("inflated_mask_hi", C.c_uint32),
+        ("max_batch", C.c_int32), ("max_frames_local", C.c_int32), ("max_tokens", C.c_int32),
+        ("max_ctx_tokens", C.c_int32), ("world_size", C.c_int32), ("rank", C.c_int32),
+        ("attn_defer_log2", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class AmGemmArgs(C.Structure):
+    _fields_ = [
+        ("A1", C.c_void_p), ("lda1", C.c_int32), ("K1", C.c_int32),
+        ("A2", C.c_void_p), ("lda2", C.c_int32),
+        ("W", C.c_void_p), ("ldw", C.c_int32),
+        ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("C", C.c_void_p), ("ldc", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32),
+        ("a_G", C.c_int32), ("a_gs", C.c_int32), ("a_off", C.c_int32),
+        ("c_G", C.c_int32), ("c_gs", C.c_int32), ("c_off", C.c_int32),
+    ]
+
+
+class AmHeadPostArgs(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int32),
+        ("rows", C.c_int64), ("seq_len", C.c_int32), ("rows_per_frame", C.c_int32),
+        ("heads", C.c_int32), ("nparts", C.c_int32), ("kinds", C.c_int32 * 3),
+        ("w_q", C.c_void_p), ("w_k", C.c_void_p), ("eps", C.c_float),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("out_q", C.c_void_p), ("sq_pad", C.c_int32),
+        ("out_k", C.c_void_p), ("out_vt", C.c_void_p), ("sk_pad", C.c_int32),
+    ]
+
+
+class AmAttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+        ("nseq", C.c_int32), ("heads", C.c_int32), ("sq", C.c_int32), ("sq_pad", C.c_int32),
+        ("sk", C.c_int32), ("sk_pad", C.c_int32), ("nchunks", C.c_int32),
+        ("chunk_stride", C.c_int64), ("ldo", C.c_int32), ("scale", C.c_float),
+        ("defer_log2", C.c_int32),
+    ]
+
+
+# every symbol include/actionmesh_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "am_last_error": (C.c_char_p, []),
+    "am_abi_version": (C.c_int, []),
+    "am_create": (C.c_int, [C.POINTER(AmConfig), C.POINTER(_P)]),
+    "am_destroy": (C.c_int, [_P]),
+    "am_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
+    "am_weights_missing": (C.c_int, [_P]),
+    "am_set_context": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "am_denoise_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "am_forward_begin": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "am_layer_pre_attn": (C.c_int, [_P, C.c_int, _P]),
+    "am_layer_post_attn": (C.c_int, [_P, C.c_int, _P]),
+    "am_forward_end": (C.c_int, [_P, _P, _P]),
+    "am_kv_chunk_elems": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "am_bind_kv_buffers": (C.c_int, [_P, _P, _P]),
+    "am_flow_step": (C.c_int, [_P, _P, C.c_int, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "am_step_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),
+    "am_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "am_head_post": (C.c_int, [C.POINTER(AmHeadPostArgs), _P]),
+    "am_attention_bf16": (C.c_int, [C.POINTER(AmAttnArgs), _P]),
+    "am_f32_to_bf16": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; fail loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C actionmesh_amd/csrc`.  actionmesh_amd has no CPU fallback."
+        )
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(l, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if l.am_abi_version() != ABI_VERSION:
+        raise HipLibraryMissing(f"ABI mismatch: library {l.am_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = l
+    return l
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().am_last_error().decode(errors="replace")
+        raise RuntimeError(f"libactionmesh_amd {what} failed (status {status}): {msg}")

@@ -1,0 +1,79 @@
+// Shared device/host helpers for libactionmesh_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/actionmesh_amd.h"
+
+typedef uint16_t bf16_t;  // raw bf16 payload
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte vector load/store unit
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+// ---- error plumbing -------------------------------------------------------
+void am_set_error(const char* fmt, ...);
+#define AM_FAIL(code, ...)        \
+  do {                            \
+    am_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+#define AM_HIP(call)                                                                    \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      AM_FAIL(AM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+#define AM_CHECK(cond, ...)                        \
+  do {                                             \
+    if (!(cond)) AM_FAIL(AM_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+#define AM_TRY(call)              \
+  do {                            \
+    int s__ = (call);             \
+    if (s__ != AM_OK) return s__; \
+  } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------
+__host__ __device__ inline float bf2f(bf16_t b) {
+  union { uint32_t u; float f; } c;
+  c.u = (uint32_t)b << 16;
+  return c.f;
+}
+__host__ __device__ inline bf16_t f2bf(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// Device-side conversions use the gfx950 hardware converter (v_cvt_pk_bf16_f32, RNE).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// round an fp32 value to bf16 precision and back (the "autocast result" rounding)
+__device__ inline float rbf(float f) { return (float)(__bf16)f; }
+__device__ inline uint32_t pack_bf2(float lo, float hi) {
+  const f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+__device__ inline float bflo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
+__device__ inline float bfhi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
+
+// exact-erf GELU (F.gelu(approximate="none"))
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Within every aligned group of 16 keys, V^T stores key k at position
+// perm16(k) = k with bits 2 and 3 swapped (an involution).  This makes the 8
+// keys a lane holds after the S^T = K Q^T MFMA ((r&3) + 8*(r>>2) + 4*hi, the
+// 32x32 C/D layout) contiguous in V^T, so the P.V MFMA A-operand is one
+// 16-byte LDS read.  See am_attention.hip.
+__host__ __device__ inline int perm16(int k) {
+  return (k & ~0xC) | ((k & 4) << 1) | ((k & 8) >> 1);
+}

@@ -1,0 +1,123 @@
+// Small fused elementwise kernels of the denoise loop.
+#include <stdarg.h>
+
+#include "am_common.h"
+
+// ---- error string (thread local) ---------------------------------------------
+static thread_local char g_err[512] = "";
+void am_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* am_last_error(void) { return g_err; }
+extern "C" int am_abi_version(void) { return 1; }
+
+namespace {
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(x + i);
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(x + i + 4);
+      u32x4_t o = {pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
+      *reinterpret_cast<u32x4_t*>(y + i) = o;
+    } else {
+      for (size_t j = i; j < n; ++j) y[j] = f2bf(x[j]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = bf2f(x[i]);
+}
+
+// diffusers Timesteps(num_channels=C, flip_sin_to_cos=False, downscale_freq_shift=0)
+// as built at temporal_denoiser.py:57-61, followed by .to(bf16) (:213).
+__global__ __launch_bounds__(256) void timestep_sinusoid_kernel(const float* __restrict__ t, bf16_t* __restrict__ out,
+                                                                int rows, int C) {
+  const int half = C / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * half) return;
+  const int r = idx / half, i = idx - r * half;
+  const float exponent = -9.210340371976184f * (float)i / (float)half;   // -ln(10000) * i / half
+  const float arg = t[r] * expf(exponent);
+  out[(int64_t)r * C + i] = f2bf(sinf(arg));
+  out[(int64_t)r * C + half + i] = f2bf(cosf(arg));
+}
+
+// aggregate_cfg (guidance.py:95-118) in bf16 + Euler step + masked write
+// (scheduler.py:238-248).  dtype flow per SURVEY.md App. C: every bf16 op result
+// is rounded to bf16; dt * v is rounded to bf16 before the fp32 latent add.
+struct FlowArgs {
+  const bf16_t* v; float* lat; int nb; float scales[3]; float dt; float sign;
+  uint8_t unobs[256]; int T; int per_frame;
+};
+__global__ __launch_bounds__(256) void flow_step_kernel(FlowArgs a) {
+  const int64_t total = (int64_t)a.T * a.per_frame;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int f = (int)(i / a.per_frame);
+  if (!a.unobs[f]) return;
+  float out = bf2f(a.v[i]);
+  float prev = out;
+  for (int b = 1; b < a.nb; ++b) {
+    const float cur = bf2f(a.v[(int64_t)b * total + i]);
+    out = rbf(out + rbf(a.scales[b - 1] * rbf(cur - prev)));
+    prev = cur;
+  }
+  a.lat[i] += a.sign * rbf(a.dt * out);
+}
+
+}  // namespace
+
+extern "C" int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream) {
+  AM_CHECK(x && y && n > 0, "am_f32_to_bf16: bad args");
+  AM_CHECK(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "am_f32_to_bf16: misaligned");
+  const int blocks = (int)std::min<size_t>((n / 8 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_bf16_to_f32(const uint16_t* x, float* y, size_t n, void* stream) {
+  AM_CHECK(x && y && n > 0, "am_bf16_to_f32: bad args");
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_timestep_sinusoid(const float* t_dev, uint16_t* out, int rows, int C, void* stream) {
+  AM_CHECK(t_dev && out && rows > 0 && C > 0 && C % 2 == 0, "am_timestep_sinusoid: bad args");
+  const int n = rows * (C / 2);
+  hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, t_dev, out, rows, C);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_flow_step(const uint16_t* v_dev, float* latents_dev, int n_branches, const float* scales_host,
+                            float dt, int is_additive, const uint8_t* unobserved_host, int T_local, int N, int Din,
+                            void* stream) {
+  AM_CHECK(v_dev && latents_dev, "am_flow_step: null operand");
+  AM_CHECK(n_branches >= 1 && n_branches <= 4, "am_flow_step: n_branches=%d", n_branches);
+  AM_CHECK(n_branches == 1 || scales_host, "am_flow_step: scales required");
+  AM_CHECK(T_local > 0 && T_local <= 256 && N > 0 && Din > 0, "am_flow_step: bad shape");
+  FlowArgs a;
+  a.v = v_dev;
+  a.lat = latents_dev;
+  a.nb = n_branches;
+  for (int i = 0; i < 3; ++i) a.scales[i] = (i < n_branches - 1) ? scales_host[i] : 0.f;
+  a.dt = dt;
+  a.sign = is_additive ? 1.f : -1.f;
+  for (int f = 0; f < 256; ++f) a.unobs[f] = (f < T_local) ? (unobserved_host ? unobserved_host[f] : 1) : 0;
+  a.T = T_local;
+  a.per_frame = N * Din;
+  const int64_t total = (int64_t)T_local * N * Din;
+  hipLaunchKernelGGL(flow_step_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}

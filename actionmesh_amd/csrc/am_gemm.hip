@@ -1,0 +1,220 @@
+// bf16 GEMM with fused epilogue for gfx950:  C = act(A @ W^T + bias) + residual
+//
+// Replaces nn.Linear (+ diffusers GELU, + residual add, + torch.cat of the skip
+// branch) on the reference hot path: block.py:131-152,
+// attention_processor.py:92-103,147, temporal_denoiser.py:206,214,242.
+//
+// Structure (round 1): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64
+// sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Operands are staged
+// global -> VGPR -> LDS (issue-early / write-late, one barrier per K-tile,
+// double-buffered LDS).  LDS rows are padded to 144 B so every ds_read_b128
+// lane group hits 16 distinct 16-byte slots.  The MFMA is issued as
+// D[n][m] = W[n][k] * A[m][k] so each lane ends with 4 consecutive output
+// columns -> 16-byte LDS writes in the epilogue, which re-reads the tile
+// row-major for fully coalesced bias/GELU/residual/store.
+#include "am_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_ROW = BK + 8;               // bf16 elements per padded LDS row (144 B)
+constexpr int TILE_ELEMS = BM * LDS_ROW;      // one operand tile, one buffer
+constexpr int CS_LD = BN + 4;                 // fp32 epilogue staging row (528 B)
+constexpr int SMEM_MAIN = 2 * 2 * TILE_ELEMS * (int)sizeof(bf16_t);   // 73728
+constexpr int SMEM_EPI = BM * CS_LD * (int)sizeof(float);             // 67584
+constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+constexpr int GROUP_M = 8;                    // m-tiles swept per pass over the W panels
+
+__device__ inline int64_t map_row(int r, int G, int gs, int off) {
+  if (G <= 0) return r;
+  int g = r / G;
+  return (int64_t)g * gs + off + (r - g * G);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Bs = As + 2 * TILE_ELEMS;
+  float* Cs = reinterpret_cast<float*>(smem);
+
+  // ---- block id -> output tile: bijective XCD remap, then grouped ordering --
+  const int nb = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  int lid;
+  {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = lid / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    const int in_g = lid - g * group_sz;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- per-thread staging addresses (4 x 16 B of A and of W per K-tile) ----
+  const bf16_t* a1p[4];
+  const bf16_t* a2p[4];
+  const bf16_t* wp[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c >> 3, col = (c & 7) * 8;
+    const int ar = min(m0 + row, p.M - 1);
+    const int64_t pr = map_row(ar, p.a_G, p.a_gs, p.a_off);
+    a1p[i] = p.A1 + pr * p.lda1 + col;
+    a2p[i] = p.A2 ? p.A2 + pr * p.lda2 + col - p.K1 : nullptr;
+    const int wr = min(n0 + row, p.N - 1);
+    wp[i] = p.W + (int64_t)wr * p.ldw + col;
+    lds_off[i] = row * LDS_ROW + col;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4_t areg[4], wreg[4];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    const bool first = k0 < p.K1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = first ? a1p[i] + k0 : a2p[i] + k0;
+      areg[i] = *reinterpret_cast<const u32x4_t*>(src);
+      wreg[i] = *reinterpret_cast<const u32x4_t*>(wp[i] + k0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4_t*>(&As[buf * TILE_ELEMS + lds_off[i]]) = areg[i];
+      *reinterpret_cast<u32x4_t*>(&Bs[buf * TILE_ELEMS + lds_off[i]]) = wreg[i];
+    }
+  };
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+
+  const int a_frag_off = (wm * 64 + l31) * LDS_ROW + hi * 8;
+  const int b_frag_off = (wn * 64 + l31) * LDS_ROW + hi * 8;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const bf16_t* Ab = As + buf * TILE_ELEMS + a_frag_off;
+    const bf16_t* Bb = Bs + buf * TILE_ELEMS + b_frag_off;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + i * 32 * LDS_ROW + ks * 16);
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(Bb + i * 32 * LDS_ROW + ks * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> coalesced fused store --------
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m = wm * 64 + i * 32 + l31;
+        const int n = wn * 64 + j * 32 + 8 * g + 4 * hi;
+        f32x4_t v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        *reinterpret_cast<f32x4_t*>(&Cs[m * CS_LD + n]) = v;
+      }
+  __syncthreads();
+
+  const int c8 = (tid & 15) * 8;
+  const int gn = n0 + c8;
+  if (gn < p.N) {
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[gn + e] : 0.f;
+#pragma unroll
+    for (int pass = 0; pass < BM / 16; ++pass) {
+      const int row = pass * 16 + (tid >> 4);
+      const int gmr = m0 + row;
+      if (gmr < p.M) {
+        const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(&Cs[row * CS_LD + c8]);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(&Cs[row * CS_LD + c8 + 4]);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);       // nn.Linear result in bf16
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = rbf(gelu_erf(v[e]));   // F.gelu on bf16 -> bf16
+        }
+        if (p.residual) {
+          const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(p.residual + pr * p.ldc + gn);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += bflo(rv[e]);
+            v[2 * e + 1] += bfhi(rv[e]);
+          }
+        }
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
+  AM_CHECK(a != nullptr, "am_gemm_bf16: null args");
+  AM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "am_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+  AM_CHECK(a->K % BK == 0, "am_gemm_bf16: K=%d must be a multiple of %d", a->K, BK);
+  AM_CHECK(a->N % 8 == 0, "am_gemm_bf16: N=%d must be a multiple of 8", a->N);
+  AM_CHECK(a->A1 && a->W && a->C, "am_gemm_bf16: null operand");
+  AM_CHECK(a->K1 > 0 && a->K1 <= a->K && a->K1 % BK == 0, "am_gemm_bf16: K1=%d invalid for K=%d", a->K1, a->K);
+  AM_CHECK(a->K1 == a->K || a->A2 != nullptr, "am_gemm_bf16: K1 < K requires A2");
+  AM_CHECK(a->lda1 % 8 == 0 && a->ldw % 8 == 0 && a->ldc % 8 == 0 && (a->A2 == nullptr || a->lda2 % 8 == 0),
+           "am_gemm_bf16: leading dimensions must be multiples of 8 elements (16 B)");
+  AM_CHECK(((uintptr_t)a->A1 | (uintptr_t)a->W | (uintptr_t)a->C | (uintptr_t)a->A2 | (uintptr_t)a->residual) % 16 == 0,
+           "am_gemm_bf16: operands must be 16-byte aligned");
+  AM_CHECK(a->act == 0 || a->act == 1, "am_gemm_bf16: unknown activation %d", a->act);
+  static bool attr_set = false;
+  if (!attr_set) {
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    attr_set = true;
+  }
+  const int tiles_m = ceil_div(a->M, BM), tiles_n = ceil_div(a->N, BN);
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), SMEM_BYTES,
+                     (hipStream_t)stream, *a, tiles_m, tiles_n);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}

@@ -1,0 +1,511 @@
+// Model-level orchestration of the Stage-I denoiser forward on one MI355X:
+// weights resident in HBM (bf16 matrices, fp32 norm/bias vectors), every
+// activation buffer pre-allocated for the bound problem size, and the forward
+// issued as a fixed sequence of the kernels in this library on the caller's
+// stream.  Mirrors ActionMeshDenoiser.forward (temporal_denoiser.py:151-249)
+// and FlowMatchingBlock.forward (block.py:110-154); the cross-attention K/V of
+// the step-invariant context are cached per window (am_set_context).
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "am_common.h"
+
+namespace {
+constexpr int HD = 128;
+inline int pad_to(int64_t x, int m) { return (int)round_up(x, m); }
+}  // namespace
+
+struct am_layer {
+  bf16_t *w_qkv = nullptr, *w_so = nullptr, *w_xq = nullptr, *w_xkv = nullptr, *w_xo = nullptr;
+  bf16_t *w_ff1 = nullptr, *w_ff2 = nullptr, *w_skip = nullptr;
+  float *b_so = nullptr, *b_xo = nullptr, *b_ff1 = nullptr, *b_ff2 = nullptr, *b_skip = nullptr;
+  float *ln_s_w = nullptr, *ln_s_b = nullptr, *ln_x_w = nullptr, *ln_x_b = nullptr;
+  float *ln_f_w = nullptr, *ln_f_b = nullptr, *ln_k_w = nullptr, *ln_k_b = nullptr;
+  float *s_nq = nullptr, *s_nk = nullptr, *x_nq = nullptr, *x_nk = nullptr;
+  bf16_t *kx = nullptr, *vtx = nullptr;   // cross-attention K / V^T cache
+};
+
+struct am_model {
+  am_config cfg;
+  int C, H, F, Dc, Din, NL, P, rank;
+  std::vector<am_layer> layers;
+  bf16_t *w_t1 = nullptr, *w_t2 = nullptr, *w_in = nullptr, *w_out = nullptr;
+  float *b_t1 = nullptr, *b_t2 = nullptr, *b_in = nullptr, *b_out = nullptr, *ln_o_w = nullptr, *ln_o_b = nullptr;
+  std::set<std::string> expected, loaded;
+  std::vector<void*> allocs;
+  float* stage_f32 = nullptr;
+  size_t stage_elems = 0;
+
+  // workspace
+  int maxB, maxT, maxN, maxS, maxL;
+  int64_t maxR;
+  bf16_t *hwork = nullptr, *z = nullptr, *ao = nullptr, *qkv = nullptr, *ffh = nullptr;
+  std::vector<bf16_t*> skip;
+  bf16_t *Qb = nullptr, *Kg = nullptr, *Vtg = nullptr;
+  bool kv_external = false;
+  size_t chunk_elems = 0;
+  bf16_t *xb = nullptr, *te0 = nullptr, *te1 = nullptr, *ctxb = nullptr, *kvtmp = nullptr;
+  float *tdev = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+
+  // per-window / per-forward state
+  bool ctx_set = false;
+  int ctxB = 0, ctxT = 0, ctxS = 0;
+  bool in_forward = false;
+  int B = 0, T = 0, N = 0, L = 0;
+  int64_t R = 0;
+  bf16_t* hsrc = nullptr;
+  int skip_top = 0;
+  int next_layer = 0;   // enforces pre/post call order
+  bool pre_done = false;
+
+  bool inflated(int i) const {
+    return i < 32 ? ((cfg.inflated_mask_lo >> i) & 1u) : ((cfg.inflated_mask_hi >> (i - 32)) & 1u);
+  }
+  bool has_skip(int i) const { return i > NL / 2; }   // temporal_denoiser.py:92
+};
+
+namespace {
+
+int dev_alloc(am_model* m, void** p, size_t bytes, bool zero = true) {
+  AM_HIP(hipMalloc(p, bytes ? bytes : 16));
+  m->allocs.push_back(*p);
+  if (zero) AM_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+  return AM_OK;
+}
+template <class T>
+int dev_alloc_t(am_model* m, T** p, size_t elems, bool zero = true) {
+  return dev_alloc(m, reinterpret_cast<void**>(p), elems * sizeof(T), zero);
+}
+
+enum WKind { W_MAT, W_BIAS, W_NORM };
+struct WSlot { void* dst; WKind kind; size_t numel; size_t dst_off; };
+
+// Reference state-dict key -> destination in our fused layout.
+bool resolve(am_model* m, const std::string& name, WSlot* s) {
+  const size_t C = m->C, F = m->F, Dc = m->Dc, Din = m->Din;
+  auto mat = [&](bf16_t* d, size_t n, size_t off = 0) { *s = {d, W_MAT, n, off}; return true; };
+  auto bias = [&](float* d, size_t n) { *s = {d, W_BIAS, n, 0}; return true; };
+  auto norm = [&](float* d, size_t n) { *s = {d, W_NORM, n, 0}; return true; };
+  if (name == "time_proj.linear_1.weight") return mat(m->w_t1, 4 * C * C);
+  if (name == "time_proj.linear_1.bias") return bias(m->b_t1, 4 * C);
+  if (name == "time_proj.linear_2.weight") return mat(m->w_t2, 4 * C * C);
+  if (name == "time_proj.linear_2.bias") return bias(m->b_t2, C);
+  if (name == "proj_in.weight") return mat(m->w_in, C * Din);
+  if (name == "proj_in.bias") return bias(m->b_in, C);
+  if (name == "norm_out.weight") return norm(m->ln_o_w, C);
+  if (name == "norm_out.bias") return norm(m->ln_o_b, C);
+  if (name == "proj_out.weight") return mat(m->w_out, Din * C);
+  if (name == "proj_out.bias") return bias(m->b_out, Din);
+  if (name.rfind("blocks.", 0) != 0) return false;
+  const size_t dot = name.find('.', 7);
+  if (dot == std::string::npos) return false;
+  int li = -1;
+  try { li = std::stoi(name.substr(7, dot - 7)); } catch (...) { return false; }
+  if (li < 0 || li >= m->NL) return false;
+  am_layer& l = m->layers[li];
+  const std::string r = name.substr(dot + 1);
+  if (r == "norm_s_attn.weight") return norm(l.ln_s_w, C);
+  if (r == "norm_s_attn.bias") return norm(l.ln_s_b, C);
+  if (r == "s_attn.norm_q.weight") return norm(l.s_nq, HD);
+  if (r == "s_attn.norm_k.weight") return norm(l.s_nk, HD);
+  // attention_processor.py:106-110: head h reads columns [384h, 384h+384) of cat(q,k,v)
+  // => the fused weight is the plain row-concatenation [Wq; Wk; Wv].
+  if (r == "s_attn.to_q.weight") return mat(l.w_qkv, C * C, 0);
+  if (r == "s_attn.to_k.weight") return mat(l.w_qkv, C * C, C * C);
+  if (r == "s_attn.to_v.weight") return mat(l.w_qkv, C * C, 2 * C * C);
+  if (r == "s_attn.to_out.0.weight") return mat(l.w_so, C * C);
+  if (r == "s_attn.to_out.0.bias") return bias(l.b_so, C);
+  if (r == "norm_x_attn.weight") return norm(l.ln_x_w, C);
+  if (r == "norm_x_attn.bias") return norm(l.ln_x_b, C);
+  if (r == "x_attn.norm_q.weight") return norm(l.x_nq, HD);
+  if (r == "x_attn.norm_k.weight") return norm(l.x_nk, HD);
+  if (r == "x_attn.to_q.weight") return mat(l.w_xq, C * C);
+  if (r == "x_attn.to_k.weight") return mat(l.w_xkv, C * Dc, 0);          // :111-115 cat(k, v)
+  if (r == "x_attn.to_v.weight") return mat(l.w_xkv, C * Dc, C * Dc);
+  if (r == "x_attn.to_out.0.weight") return mat(l.w_xo, C * C);
+  if (r == "x_attn.to_out.0.bias") return bias(l.b_xo, C);
+  if (r == "norm_ff.weight") return norm(l.ln_f_w, C);
+  if (r == "norm_ff.bias") return norm(l.ln_f_b, C);
+  if (r == "ff.net.0.proj.weight") return mat(l.w_ff1, F * C);
+  if (r == "ff.net.0.proj.bias") return bias(l.b_ff1, F);
+  if (r == "ff.net.2.weight") return mat(l.w_ff2, C * F);
+  if (r == "ff.net.2.bias") return bias(l.b_ff2, C);
+  if (m->has_skip(li)) {
+    if (r == "norm_skip.weight") return norm(l.ln_k_w, C);
+    if (r == "norm_skip.bias") return norm(l.ln_k_b, C);
+    if (r == "linear_skip.weight") return mat(l.w_skip, 2 * C * C);
+    if (r == "linear_skip.bias") return bias(l.b_skip, C);
+  }
+  return false;
+}
+
+void build_expected(am_model* m) {
+  auto& e = m->expected;
+  for (const char* n : {"time_proj.linear_1.weight", "time_proj.linear_1.bias", "time_proj.linear_2.weight",
+                        "time_proj.linear_2.bias", "proj_in.weight", "proj_in.bias", "norm_out.weight",
+                        "norm_out.bias", "proj_out.weight", "proj_out.bias"})
+    e.insert(n);
+  for (int i = 0; i < m->NL; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    for (const char* n :
+         {"norm_s_attn.weight", "norm_s_attn.bias", "s_attn.norm_q.weight", "s_attn.norm_k.weight",
+          "s_attn.to_q.weight", "s_attn.to_k.weight", "s_attn.to_v.weight", "s_attn.to_out.0.weight",
+          "s_attn.to_out.0.bias", "norm_x_attn.weight", "norm_x_attn.bias", "x_attn.norm_q.weight",
+          "x_attn.norm_k.weight", "x_attn.to_q.weight", "x_attn.to_k.weight", "x_attn.to_v.weight",
+          "x_attn.to_out.0.weight", "x_attn.to_out.0.bias", "norm_ff.weight", "norm_ff.bias",
+          "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff.net.2.weight", "ff.net.2.bias"})
+      e.insert(p + n);
+    if (m->has_skip(i))
+      for (const char* n : {"norm_skip.weight", "norm_skip.bias", "linear_skip.weight", "linear_skip.bias"})
+        e.insert(p + n);
+  }
+}
+
+int gemm(hipStream_t st, const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const bf16_t* res,
+         bf16_t* Cp, int ldc, int64_t M, int N, int K, int act, const bf16_t* A2 = nullptr, int lda2 = 0, int K1 = 0,
+         int aG = 0, int ags = 0, int aoff = 0, int cG = 0, int cgs = 0, int coff = 0) {
+  am_gemm_args g;
+  g.A1 = A; g.lda1 = lda; g.K1 = A2 ? K1 : K;
+  g.A2 = A2; g.lda2 = lda2;
+  g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.C = Cp; g.ldc = ldc;
+  g.M = (int)M; g.N = N; g.K = K; g.act = act;
+  g.a_G = aG; g.a_gs = ags; g.a_off = aoff;
+  g.c_G = cG; g.c_gs = cgs; g.c_off = coff;
+  return am_gemm_bf16(&g, st);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int am_create(const am_config* cfg, am_handle* out) {
+  AM_CHECK(cfg && out, "am_create: null argument");
+  AM_CHECK(cfg->num_heads > 0 && cfg->width == cfg->num_heads * HD, "am_create: width=%d must equal heads=%d * 128",
+           cfg->width, cfg->num_heads);
+  AM_CHECK(cfg->num_layers > 0 && cfg->num_layers <= 64, "am_create: num_layers=%d", cfg->num_layers);
+  AM_CHECK(cfg->in_channels % 64 == 0 && cfg->in_channels > 0, "am_create: in_channels=%d must be a multiple of 64", cfg->in_channels);
+  AM_CHECK(cfg->cross_dim % 64 == 0 && cfg->cross_dim > 0, "am_create: cross_dim=%d must be a multiple of 64", cfg->cross_dim);
+  AM_CHECK(cfg->ff_inner % 64 == 0 && cfg->ff_inner > 0, "am_create: ff_inner=%d must be a multiple of 64", cfg->ff_inner);
+  AM_CHECK(cfg->max_batch > 0 && cfg->max_frames_local > 0 && cfg->max_tokens > 0 && cfg->max_ctx_tokens > 0,
+           "am_create: workspace bounds must be positive");
+  AM_CHECK(cfg->world_size >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world_size, "am_create: rank %d / world %d",
+           cfg->rank, cfg->world_size);
+  AM_CHECK(cfg->attn_defer_log2 == 0 || cfg->attn_defer_log2 == 8, "am_create: attn_defer_log2 must be 0 or 8");
+  int ndev = 0;
+  AM_HIP(hipGetDeviceCount(&ndev));
+  AM_CHECK(ndev > 0, "am_create: no HIP device visible (this library has no CPU path)");
+
+  am_model* m = new am_model();
+  m->cfg = *cfg;
+  m->C = cfg->width; m->H = cfg->num_heads; m->F = cfg->ff_inner; m->Dc = cfg->cross_dim;
+  m->Din = cfg->in_channels; m->NL = cfg->num_layers; m->P = cfg->world_size; m->rank = cfg->rank;
+  m->layers.resize(m->NL);
+  build_expected(m);
+  const size_t C = m->C, F = m->F, Dc = m->Dc, Din = m->Din;
+  int st = AM_OK;
+#define A_(call) do { if (st == AM_OK) st = (call); } while (0)
+  A_(dev_alloc_t(m, &m->w_t1, 4 * C * C)); A_(dev_alloc_t(m, &m->b_t1, 4 * C));
+  A_(dev_alloc_t(m, &m->w_t2, 4 * C * C)); A_(dev_alloc_t(m, &m->b_t2, C));
+  A_(dev_alloc_t(m, &m->w_in, C * Din)); A_(dev_alloc_t(m, &m->b_in, C));
+  A_(dev_alloc_t(m, &m->w_out, Din * C)); A_(dev_alloc_t(m, &m->b_out, Din));
+  A_(dev_alloc_t(m, &m->ln_o_w, C)); A_(dev_alloc_t(m, &m->ln_o_b, C));
+
+  // workspace bounds
+  m->maxB = cfg->max_batch; m->maxT = cfg->max_frames_local; m->maxN = cfg->max_tokens; m->maxS = cfg->max_ctx_tokens;
+  m->maxL = m->maxN + 1;
+  m->maxR = (int64_t)m->maxB * m->maxT * m->maxL;
+  const int64_t BT = (int64_t)m->maxB * m->maxT;
+  const int Spad = pad_to(m->maxS, 64);
+  for (int i = 0; i < m->NL && st == AM_OK; ++i) {
+    am_layer& l = m->layers[i];
+    A_(dev_alloc_t(m, &l.w_qkv, 3 * C * C)); A_(dev_alloc_t(m, &l.w_so, C * C)); A_(dev_alloc_t(m, &l.b_so, C));
+    A_(dev_alloc_t(m, &l.w_xq, C * C)); A_(dev_alloc_t(m, &l.w_xkv, 2 * C * Dc));
+    A_(dev_alloc_t(m, &l.w_xo, C * C)); A_(dev_alloc_t(m, &l.b_xo, C));
+    A_(dev_alloc_t(m, &l.w_ff1, F * C)); A_(dev_alloc_t(m, &l.b_ff1, F));
+    A_(dev_alloc_t(m, &l.w_ff2, C * F)); A_(dev_alloc_t(m, &l.b_ff2, C));
+    A_(dev_alloc_t(m, &l.ln_s_w, C)); A_(dev_alloc_t(m, &l.ln_s_b, C));
+    A_(dev_alloc_t(m, &l.ln_x_w, C)); A_(dev_alloc_t(m, &l.ln_x_b, C));
+    A_(dev_alloc_t(m, &l.ln_f_w, C)); A_(dev_alloc_t(m, &l.ln_f_b, C));
+    A_(dev_alloc_t(m, &l.s_nq, (size_t)HD)); A_(dev_alloc_t(m, &l.s_nk, (size_t)HD));
+    A_(dev_alloc_t(m, &l.x_nq, (size_t)HD)); A_(dev_alloc_t(m, &l.x_nk, (size_t)HD));
+    if (m->has_skip(i)) {
+      A_(dev_alloc_t(m, &l.w_skip, 2 * C * C)); A_(dev_alloc_t(m, &l.b_skip, C));
+      A_(dev_alloc_t(m, &l.ln_k_w, C)); A_(dev_alloc_t(m, &l.ln_k_b, C));
+    }
+    A_(dev_alloc_t(m, &l.kx, (size_t)BT * m->H * Spad * HD));
+    A_(dev_alloc_t(m, &l.vtx, (size_t)BT * m->H * HD * Spad));
+  }
+  const size_t R = (size_t)m->maxR;
+  A_(dev_alloc_t(m, &m->hwork, R * C)); A_(dev_alloc_t(m, &m->z, R * C)); A_(dev_alloc_t(m, &m->ao, R * C));
+  A_(dev_alloc_t(m, &m->qkv, R * 3 * C)); A_(dev_alloc_t(m, &m->ffh, R * F));
+  m->skip.resize(m->NL / 2, nullptr);
+  for (int i = 0; i < m->NL / 2; ++i) A_(dev_alloc_t(m, &m->skip[i], R * C));
+  {
+    const size_t q_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 256) * HD;
+    const size_t q_frm = (size_t)BT * m->H * pad_to(m->maxL, 256) * HD;
+    A_(dev_alloc_t(m, &m->Qb, q_inf > q_frm ? q_inf : q_frm));
+    const size_t k_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 64) * HD;
+    const size_t k_frm = (size_t)BT * m->H * pad_to(m->maxL, 64) * HD;
+    m->chunk_elems = k_inf > k_frm ? k_inf : k_frm;
+  }
+  A_(dev_alloc_t(m, &m->xb, (size_t)BT * m->maxN * Din));
+  A_(dev_alloc_t(m, &m->te0, (size_t)BT * C)); A_(dev_alloc_t(m, &m->te1, (size_t)BT * 4 * C));
+  A_(dev_alloc_t(m, &m->tdev, (size_t)BT));
+  A_(dev_alloc_t(m, &m->ctxb, (size_t)BT * m->maxS * Dc)); A_(dev_alloc_t(m, &m->kvtmp, (size_t)BT * m->maxS * 2 * C));
+  A_(dev_alloc_t(m, &m->rope_cos, (size_t)BT * 64)); A_(dev_alloc_t(m, &m->rope_sin, (size_t)BT * 64));
+#undef A_
+  if (st != AM_OK) {
+    am_destroy(m);
+    return st;
+  }
+  *out = m;
+  return AM_OK;
+}
+
+extern "C" int am_destroy(am_handle h) {
+  if (!h) return AM_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->stage_f32) (void)hipFree(h->stage_f32);
+  delete h;
+  return AM_OK;
+}
+
+extern "C" int am_load_weight(am_handle h, const char* name, const float* host, size_t numel) {
+  AM_CHECK(h && name && host, "am_load_weight: null argument");
+  WSlot s;
+  if (!resolve(h, name, &s)) AM_FAIL(AM_ERR_NOTFOUND, "am_load_weight: unknown state-dict key '%s'", name);
+  AM_CHECK(numel == s.numel, "am_load_weight: '%s' has %zu elements, expected %zu", name, numel, s.numel);
+  if (s.kind == W_MAT) {
+    if (h->stage_elems < numel) {
+      if (h->stage_f32) AM_HIP(hipFree(h->stage_f32));
+      h->stage_f32 = nullptr; h->stage_elems = 0;
+      AM_HIP(hipMalloc(reinterpret_cast<void**>(&h->stage_f32), numel * sizeof(float)));
+      h->stage_elems = numel;
+    }
+    AM_HIP(hipMemcpy(h->stage_f32, host, numel * sizeof(float), hipMemcpyHostToDevice));
+    AM_TRY(am_f32_to_bf16(h->stage_f32, reinterpret_cast<bf16_t*>(s.dst) + s.dst_off, numel, nullptr));
+    AM_HIP(hipStreamSynchronize(nullptr));
+  } else {
+    std::vector<float> tmp(host, host + numel);
+    if (s.kind == W_BIAS)   // autocast casts the bias to bf16 with the weight
+      for (auto& v : tmp) v = bf2f(f2bf(v));
+    AM_HIP(hipMemcpy(s.dst, tmp.data(), numel * sizeof(float), hipMemcpyHostToDevice));
+  }
+  h->loaded.insert(name);
+  return AM_OK;
+}
+
+extern "C" int am_weights_missing(am_handle h) {
+  if (!h) return -1;
+  int missing = 0;
+  for (const auto& n : h->expected)
+    if (!h->loaded.count(n)) ++missing;
+  return missing;
+}
+
+extern "C" int am_kv_chunk_elems(am_handle h, size_t* elems) {
+  AM_CHECK(h && elems, "am_kv_chunk_elems: null argument");
+  *elems = h->chunk_elems;
+  return AM_OK;
+}
+
+extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev) {
+  AM_CHECK(h && k_dev && vt_dev, "am_bind_kv_buffers: null argument");
+  AM_CHECK(((uintptr_t)k_dev | (uintptr_t)vt_dev) % 16 == 0, "am_bind_kv_buffers: misaligned");
+  h->Kg = k_dev; h->Vtg = vt_dev; h->kv_external = true;
+  return AM_OK;
+}
+
+static int ensure_kv(am_model* m) {
+  if (m->Kg) return AM_OK;
+  AM_TRY(dev_alloc_t(m, &m->Kg, m->chunk_elems * (size_t)m->P));
+  AM_TRY(dev_alloc_t(m, &m->Vtg, m->chunk_elems * (size_t)m->P));
+  return AM_OK;
+}
+
+extern "C" int am_set_context(am_handle h, const float* ctx_dev, int B, int T, int S, const float* cos_host,
+                              const float* sin_host, void* stream) {
+  AM_CHECK(h && ctx_dev && cos_host && sin_host, "am_set_context: null argument");
+  if (am_weights_missing(h) != 0) AM_FAIL(AM_ERR_STATE, "am_set_context: %d weights not loaded", am_weights_missing(h));
+  AM_CHECK(B > 0 && B <= h->maxB && T > 0 && T <= h->maxT && S > 0 && S <= h->maxS,
+           "am_set_context: (B=%d,T=%d,S=%d) exceeds workspace (%d,%d,%d)", B, T, S, h->maxB, h->maxT, h->maxS);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t BT = (int64_t)B * T;
+  AM_HIP(hipMemcpyAsync(h->rope_cos, cos_host, BT * 64 * sizeof(float), hipMemcpyHostToDevice, st));
+  AM_HIP(hipMemcpyAsync(h->rope_sin, sin_host, BT * 64 * sizeof(float), hipMemcpyHostToDevice, st));
+  AM_TRY(am_f32_to_bf16(ctx_dev, h->ctxb, (size_t)BT * S * h->Dc, st));
+  const int Spad = pad_to(S, 64);
+  for (int i = 0; i < h->NL; ++i) {
+    am_layer& l = h->layers[i];
+    AM_TRY(gemm(st, h->ctxb, h->Dc, l.w_xkv, h->Dc, nullptr, nullptr, h->kvtmp, 2 * h->C, BT * S, 2 * h->C, h->Dc, 0));
+    am_headpost_args hp = {};
+    hp.X = h->kvtmp; hp.ldx = 2 * h->C; hp.rows = BT * S; hp.seq_len = S; hp.rows_per_frame = S;
+    hp.heads = h->H; hp.nparts = 2; hp.kinds[0] = 1; hp.kinds[1] = 2;
+    hp.w_q = nullptr; hp.w_k = l.x_nk; hp.eps = 1e-6f;
+    hp.out_k = l.kx; hp.out_vt = l.vtx; hp.sk_pad = Spad;
+    AM_TRY(am_head_post(&hp, st));
+  }
+  h->ctx_set = true; h->ctxB = B; h->ctxT = T; h->ctxS = S;
+  return AM_OK;
+}
+
+extern "C" int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T, int N, void* stream) {
+  AM_CHECK(h && x_dev && t_bt_host, "am_forward_begin: null argument");
+  if (!h->ctx_set) AM_FAIL(AM_ERR_STATE, "am_forward_begin: am_set_context has not been called");
+  AM_CHECK(B == h->ctxB && T == h->ctxT, "am_forward_begin: (B=%d,T=%d) differs from the bound context (%d,%d)", B, T, h->ctxB, h->ctxT);
+  AM_CHECK(N > 0 && N <= h->maxN, "am_forward_begin: N=%d exceeds workspace %d", N, h->maxN);
+  AM_TRY(ensure_kv(h));
+  hipStream_t st = (hipStream_t)stream;
+  const int C = h->C, Din = h->Din;
+  h->B = B; h->T = T; h->N = N; h->L = N + 1; h->R = (int64_t)B * T * h->L;
+  const int64_t BT = (int64_t)B * T;
+  AM_HIP(hipMemcpyAsync(h->tdev, t_bt_host, BT * sizeof(float), hipMemcpyHostToDevice, st));
+  // proj_in (temporal_denoiser.py:205-206) written behind each frame's time token (:217)
+  AM_TRY(am_f32_to_bf16(x_dev, h->xb, (size_t)BT * N * Din, st));
+  AM_TRY(gemm(st, h->xb, Din, h->w_in, Din, h->b_in, nullptr, h->hwork, C, BT * N, C, Din, 0, nullptr, 0, 0, 0, 0, 0,
+              /*cG*/ N, /*cgs*/ h->L, /*coff*/ 1));
+  // time token (:213-217): sinusoid -> Linear -> GELU -> Linear -> row 0 of each frame
+  AM_TRY(am_timestep_sinusoid(h->tdev, h->te0, (int)BT, C, st));
+  AM_TRY(gemm(st, h->te0, C, h->w_t1, C, h->b_t1, nullptr, h->te1, 4 * C, BT, 4 * C, C, 1));
+  AM_TRY(gemm(st, h->te1, 4 * C, h->w_t2, 4 * C, h->b_t2, nullptr, h->hwork, C, BT, C, 4 * C, 0, nullptr, 0, 0, 0, 0, 0,
+              /*cG*/ 1, /*cgs*/ h->L, /*coff*/ 0));
+  h->hsrc = h->hwork;
+  h->skip_top = 0;
+  h->next_layer = 0;
+  h->pre_done = false;
+  h->in_forward = true;
+  return AM_OK;
+}
+
+extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
+  AM_CHECK(h, "am_layer_pre_attn: null handle");
+  if (!h->in_forward || i != h->next_layer || h->pre_done)
+    AM_FAIL(AM_ERR_STATE, "am_layer_pre_attn: layer %d out of order (next=%d)", i, h->next_layer);
+  hipStream_t st = (hipStream_t)stream;
+  am_layer& l = h->layers[i];
+  const int C = h->C, L = h->L;
+  const int64_t R = h->R;
+  if (h->has_skip(i)) {   // block.py:131-133
+    AM_CHECK(h->skip_top > 0, "am_layer_pre_attn: skip stack empty at layer %d", i);
+    const bf16_t* sk = h->skip[--h->skip_top];
+    AM_TRY(gemm(st, sk, C, l.w_skip, 2 * C, l.b_skip, nullptr, h->z, C, R, C, 2 * C, 0, h->hsrc, C, C));
+    AM_TRY(am_layernorm_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, st));
+    h->hsrc = h->hwork;
+  }
+  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, R, C, 1e-5f, st));      // block.py:138
+  AM_TRY(gemm(st, h->z, C, l.w_qkv, C, nullptr, nullptr, h->qkv, 3 * C, R, 3 * C, C, 0));   // :92-103
+  am_headpost_args hp = {};
+  hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = R; hp.rows_per_frame = L;
+  hp.heads = h->H; hp.nparts = 3; hp.kinds[0] = 0; hp.kinds[1] = 1; hp.kinds[2] = 2;
+  hp.w_q = l.s_nq; hp.w_k = l.s_nk; hp.eps = 1e-6f;
+  hp.rope_cos = h->rope_cos; hp.rope_sin = h->rope_sin;
+  hp.out_q = h->Qb;
+  if (h->inflated(i)) {
+    hp.seq_len = h->T * L;
+    hp.sq_pad = pad_to(hp.seq_len, 256); hp.sk_pad = pad_to(hp.seq_len, 64);
+    hp.out_k = h->Kg + (size_t)h->rank * h->chunk_elems;
+    hp.out_vt = h->Vtg + (size_t)h->rank * h->chunk_elems;
+  } else {
+    hp.seq_len = L;
+    hp.sq_pad = pad_to(L, 256); hp.sk_pad = pad_to(L, 64);
+    hp.out_k = h->Kg; hp.out_vt = h->Vtg;
+  }
+  AM_TRY(am_head_post(&hp, st));
+  h->pre_done = true;
+  return AM_OK;
+}
+
+extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
+  AM_CHECK(h, "am_layer_post_attn: null handle");
+  if (!h->in_forward || i != h->next_layer || !h->pre_done)
+    AM_FAIL(AM_ERR_STATE, "am_layer_post_attn: layer %d out of order (next=%d)", i, h->next_layer);
+  hipStream_t st = (hipStream_t)stream;
+  am_layer& l = h->layers[i];
+  const int C = h->C, L = h->L, F = h->F;
+  const int64_t R = h->R;
+  const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+  // ---- self-attention (attention_processor.py:133-166) ------------------------
+  am_attn_args at = {};
+  at.Q = h->Qb; at.K = h->Kg; at.Vt = h->Vtg; at.O = h->ao;
+  at.heads = h->H; at.ldo = C; at.scale = scale; at.defer_log2 = h->cfg.attn_defer_log2;
+  if (h->inflated(i)) {
+    at.nseq = h->B; at.sq = h->T * L; at.sq_pad = pad_to(at.sq, 256);
+    at.sk = h->T * L; at.sk_pad = pad_to(at.sk, 64);
+    at.nchunks = h->P; at.chunk_stride = (int64_t)h->chunk_elems;
+  } else {
+    at.nseq = h->B * h->T; at.sq = L; at.sq_pad = pad_to(L, 256);
+    at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
+  }
+  AM_TRY(am_attention_bf16(&at, st));
+  AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, R, C, C, 0));   // to_out + residual (block.py:137)
+  h->hsrc = h->hwork;
+  // ---- cross-attention to the frame's own context tokens (block.py:146-149) ----
+  AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_x_w, l.ln_x_b, R, C, 1e-5f, st));
+  AM_TRY(gemm(st, h->z, C, l.w_xq, C, nullptr, nullptr, h->qkv, C, R, C, C, 0));
+  am_headpost_args hp = {};
+  hp.X = h->qkv; hp.ldx = C; hp.rows = R; hp.seq_len = L; hp.rows_per_frame = L;
+  hp.heads = h->H; hp.nparts = 1; hp.kinds[0] = 0;
+  hp.w_q = l.x_nq; hp.eps = 1e-6f;
+  hp.out_q = h->Qb; hp.sq_pad = pad_to(L, 256);
+  AM_TRY(am_head_post(&hp, st));
+  am_attn_args ax = {};
+  ax.Q = h->Qb; ax.K = l.kx; ax.Vt = l.vtx; ax.O = h->ao;
+  ax.nseq = h->B * h->T; ax.heads = h->H; ax.sq = L; ax.sq_pad = pad_to(L, 256);
+  ax.sk = h->ctxS; ax.sk_pad = pad_to(h->ctxS, 64); ax.nchunks = 1; ax.chunk_stride = 0;
+  ax.ldo = C; ax.scale = scale; ax.defer_log2 = h->cfg.attn_defer_log2;
+  AM_TRY(am_attention_bf16(&ax, st));
+  AM_TRY(gemm(st, h->ao, C, l.w_xo, C, l.b_xo, h->hwork, h->hwork, C, R, C, C, 0));
+  // ---- feed-forward (block.py:152; diffusers FeedForward "gelu") ------------------
+  AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_f_w, l.ln_f_b, R, C, 1e-5f, st));
+  AM_TRY(gemm(st, h->z, C, l.w_ff1, C, l.b_ff1, nullptr, h->ffh, F, R, F, C, 1));
+  bf16_t* dst = h->hwork;
+  if (i < h->NL / 2) dst = h->skip[h->skip_top++];     // temporal_denoiser.py:231-232 (kept, not copied)
+  AM_TRY(gemm(st, h->ffh, F, l.w_ff2, F, l.b_ff2, h->hwork, dst, C, R, C, F, 0));
+  h->hsrc = dst;
+  h->next_layer = i + 1;
+  h->pre_done = false;
+  return AM_OK;
+}
+
+extern "C" int am_forward_end(am_handle h, uint16_t* v_out, void* stream) {
+  AM_CHECK(h && v_out, "am_forward_end: null argument");
+  if (!h->in_forward || h->next_layer != h->NL) AM_FAIL(AM_ERR_STATE, "am_forward_end: %d of %d layers run", h->next_layer, h->NL);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = h->C;
+  // norm_out -> drop the time token -> proj_out (temporal_denoiser.py:239-242)
+  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, h->ln_o_w, h->ln_o_b, h->R, C, 1e-5f, st));
+  AM_TRY(gemm(st, h->z, C, h->w_out, C, h->b_out, nullptr, v_out, h->Din, (int64_t)h->B * h->T * h->N, h->Din, C, 0,
+              nullptr, 0, 0, /*aG*/ h->N, /*ags*/ h->L, /*aoff*/ 1));
+  h->in_forward = false;
+  return AM_OK;
+}
+
+extern "C" int am_denoise_forward(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T, int N,
+                                  uint16_t* v_out, void* stream) {
+  AM_CHECK(h, "am_denoise_forward: null handle");
+  if (h->P != 1) AM_FAIL(AM_ERR_STATE, "am_denoise_forward: world_size=%d needs the split API with a K/V all-gather", h->P);
+  AM_TRY(am_forward_begin(h, x_dev, t_bt_host, B, T, N, stream));
+  for (int i = 0; i < h->NL; ++i) {
+    AM_TRY(am_layer_pre_attn(h, i, stream));
+    AM_TRY(am_layer_post_attn(h, i, stream));
+  }
+  return am_forward_end(h, v_out, stream);
+}
+
+extern "C" double am_step_flops(am_handle h, int B, int T, int N, int S) {
+  if (!h) return 0.0;
+  const double C = h->C, F = h->F, Dc = h->Dc, Din = h->Din;
+  const double TL = (double)T * (N + 1);
+  double tot = 0.0;
+  for (int i = 0; i < h->NL; ++i) {
+    const double attn = h->inflated(i) ? 4.0 * TL * TL * C : 4.0 * T * (double)(N + 1) * (N + 1) * C;
+    double per = 6.0 * TL * C * C + attn + 2.0 * TL * C * C;
+    per += 2.0 * TL * C * C + 4.0 * T * S * Dc * C + 4.0 * TL * S * C + 2.0 * TL * C * C;
+    per += 4.0 * TL * C * F;
+    if (h->has_skip(i)) per += 4.0 * TL * C * C;
+    tot += per;
+  }
+  tot += 4.0 * T * N * Din * C + 16.0 * T * C * C;
+  return B * tot;
+}

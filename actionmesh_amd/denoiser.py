@@ -1,0 +1,300 @@
+"""HipDenoiser: drop-in for actionmesh.model.temporal_denoiser.ActionMeshDenoiser
+(reference temporal_denoiser.py:23-249) whose forward runs in libactionmesh_amd.so.
+
+Same constructor fields, same `forward(hidden_states, context, framestep,
+diffusion_time, mask=None, freqs_rot=None) -> (velocity, freqs_rot)`, `.device`,
+`.eval()`, `.to()`, `load_state_dict` with the reference's state-dict keys and
+`from_pretrained(dir)`.  Python here only marshals pointers; there is no torch
+arithmetic on the hot path and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _lib as L
+from .sharding import FrameShardPlan, gather_frames, sharded_forward
+
+HEAD_DIM = 128
+
+
+def rope_tables_host(framestep: torch.Tensor, head_dim: int = HEAD_DIM) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host restatement of precompute_freqs_rot (temporal_denoiser.py:114-149): positions =
+    framestep - min_t framestep (embeddings.py:135-153), angle_i = pos * 10000^(-2i/hd)
+    (rotary_embedding.py:10-69).  Returns cos, sin of shape (B*T, hd/2) fp32: one value per
+    interleaved pair; every token of a frame (incl. the time token) shares its frame's angle."""
+    fs = framestep.detach().float().cpu()
+    pos = (fs - fs.min(dim=1).values[:, None]).reshape(-1)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    phases = torch.outer(pos, inv_freq)
+    return phases.cos().contiguous(), phases.sin().contiguous()
+
+
+def masked_time(diffusion_time: Sequence[float], mask: Optional[torch.Tensor], B: int, T: int) -> List[float]:
+    """temporal_denoiser.py:209-212: t.repeat(T) (b-fastest) * (1 - merged mask) ((b t) order)."""
+    t_rep = [float(diffusion_time[i % B]) for i in range(B * T)]
+    if mask is None:
+        return t_rep
+    m = mask.detach().float().cpu().reshape(B * T).tolist()
+    return [t * (1.0 - mm) for t, mm in zip(t_rep, m)]
+
+
+class WindowCache:
+    """Opaque `freqs_rot` object handed back to the sampler (scheduler.py:224-232): proves that
+    the step-invariant state (RoPE table + cross-attention K/V cache) of this window is bound."""
+
+    def __init__(self, generation: int):
+        self.generation = generation
+
+
+class HipEngine:
+    """Owns one am_handle (weights + workspace on one GPU) and exposes the phase protocol
+    of sharding.Engine."""
+
+    def __init__(self, hp: Dict, state_dict: Dict[str, torch.Tensor], device: torch.device,
+                 max_batch: int, frames_local: int, tokens: int, ctx_tokens: int,
+                 world: int = 1, rank: int = 0, attn_defer_log2: int = 8):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipEngine needs a ROCm device (torch device type 'cuda'); there is no CPU path")
+        self.hp = dict(hp)
+        self.num_layers = hp["num_layers"]
+        self.inflated = set(hp["inflated_layers"])
+        self.bounds = (max_batch, frames_local, tokens, ctx_tokens)
+        self.world, self.rank = world, rank
+        cfg = L.AmConfig()
+        cfg.in_channels = hp["in_channels"]; cfg.num_layers = hp["num_layers"]
+        cfg.num_heads = hp["num_attention_heads"]; cfg.width = hp["width"]
+        cfg.ff_inner = int(hp["width"] * hp["mlp_ratio"]); cfg.cross_dim = hp["cross_attention_dim"]
+        mask = 0
+        for i in self.inflated:
+            mask |= 1 << i
+        cfg.inflated_mask_lo = mask & 0xFFFFFFFF; cfg.inflated_mask_hi = (mask >> 32) & 0xFFFFFFFF
+        cfg.max_batch, cfg.max_frames_local, cfg.max_tokens, cfg.max_ctx_tokens = self.bounds
+        cfg.world_size, cfg.rank = world, rank
+        cfg.attn_defer_log2 = attn_defer_log2
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_create(C.byref(cfg), C.byref(self.handle)), "am_create")
+            for name, t in state_dict.items():
+                t = t.detach().to("cpu", torch.float32).contiguous()
+                L.check(self.lib.am_load_weight(self.handle, name.encode(), t.data_ptr(), t.numel()),
+                        f"am_load_weight({name})")
+            missing = self.lib.am_weights_missing(self.handle)
+            if missing:
+                raise RuntimeError(f"HipEngine: {missing} reference state-dict keys were not provided")
+            self._kv = None
+            if world > 1:
+                n = C.c_size_t()
+                L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
+                k = torch.zeros((world, n.value), dtype=torch.bfloat16, device=self.device)
+                vt = torch.zeros((world, n.value), dtype=torch.bfloat16, device=self.device)
+                L.check(self.lib.am_bind_kv_buffers(self.handle, k.data_ptr(), vt.data_ptr()), "am_bind_kv_buffers")
+                self._kv = (k, vt)
+        self._shape = None
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.am_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fits(self, B: int, T: int, N: int, S: int) -> bool:
+        b = self.bounds
+        return B <= b[0] and T <= b[1] and N <= b[2] and S <= b[3]
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def is_inflated(self, layer: int) -> bool:
+        return layer in self.inflated
+
+    def kv_buffers(self):
+        return self._kv
+
+    def set_context(self, ctx_local: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> None:
+        """ctx_local (B, T_local, S, Dc) fp32 device; cos/sin (B*T_local, 64) fp32 host."""
+        B, T, S, _ = ctx_local.shape
+        ctx_local = ctx_local.to(self.device, torch.float32).contiguous()
+        cos = cos.contiguous(); sin = sin.contiguous()
+        assert cos.shape == (B * T, HEAD_DIM // 2) and not cos.is_cuda
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_set_context(self.handle, ctx_local.data_ptr(), B, T, S,
+                                            cos.data_ptr(), sin.data_ptr(), self._stream()), "am_set_context")
+        self._ctx_keepalive = ctx_local
+
+    def begin(self, x_local: torch.Tensor, t_bt_local: List[float]) -> None:
+        B, T, N, D = x_local.shape
+        x_local = x_local.to(self.device, torch.float32).contiguous()
+        t = (C.c_float * (B * T))(*t_bt_local)
+        self._shape = (B, T, N, D)
+        self._x_keepalive = x_local
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_forward_begin(self.handle, x_local.data_ptr(), t, B, T, N, self._stream()),
+                    "am_forward_begin")
+
+    def layer_pre(self, layer: int) -> None:
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_layer_pre_attn(self.handle, layer, self._stream()), "am_layer_pre_attn")
+
+    def layer_post(self, layer: int) -> None:
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_layer_post_attn(self.handle, layer, self._stream()), "am_layer_post_attn")
+
+    def end(self) -> torch.Tensor:
+        B, T, N, D = self._shape
+        v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_forward_end(self.handle, v.data_ptr(), self._stream()), "am_forward_end")
+        return v
+
+    def forward(self, x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
+        """Single-rank convenience: the whole forward in one C call."""
+        B, T, N, D = x_local.shape
+        x_local = x_local.to(self.device, torch.float32).contiguous()
+        t = (C.c_float * (B * T))(*t_bt_local)
+        v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),
+                                                self._stream()), "am_denoise_forward")
+        return v
+
+    def step_flops(self, B: int, T_total: int, N: int, S: int) -> float:
+        return float(self.lib.am_step_flops(self.handle, B, T_total, N, S))
+
+
+class HipDenoiser(nn.Module):
+    """Drop-in replacement of ActionMeshDenoiser (see module docstring).
+
+    `process_group`: when given (world > 1) the frames of each call are sharded across the
+    group's ranks (one process per GPU) and the K/V all-gather runs on RCCL; every rank
+    passes the full (B, T, ...) tensors and receives the full velocity, like the reference.
+    """
+
+    def __init__(self, num_tokens_nominal: int = 2048, temporal_context_size: int = 16,
+                 in_channels: int = 64, num_layers: int = 21, num_attention_heads: int = 16,
+                 width: int = 2048, mlp_ratio: float = 4.0, cross_attention_dim: int = 1024,
+                 inflated_layers: Optional[Sequence[int]] = None, clear_autocast: bool = True,
+                 compile_blocks: bool = False, compile_mode: str = "default",
+                 process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8):
+        super().__init__()
+        if width != num_attention_heads * HEAD_DIM:
+            raise ValueError("HipDenoiser supports head_dim 128 only (width = heads * 128), as the reference ships")
+        self.num_tokens_nominal = num_tokens_nominal
+        self.temporal_context_size = temporal_context_size
+        self.in_channels = in_channels
+        self.out_channels = in_channels
+        self.num_layers = num_layers
+        self.num_attention_heads = num_attention_heads
+        self.width = width
+        self.width_per_head = HEAD_DIM
+        self.mlp_ratio = mlp_ratio
+        self.cross_attention_dim = cross_attention_dim
+        self.inflated_layers = tuple(range(num_layers)) if inflated_layers is None else tuple(inflated_layers)
+        self.attn_defer_log2 = attn_defer_log2
+        self.process_group = process_group
+        self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
+        self._host_sd: Optional[Dict[str, torch.Tensor]] = None
+        self._engine: Optional[HipEngine] = None
+        self._generation = 0
+        self._window: Optional[WindowCache] = None
+
+    # ---- reference-compatible surface ------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self._device_probe.device
+
+    def hyper_params(self) -> Dict:
+        return dict(in_channels=self.in_channels, num_layers=self.num_layers,
+                    num_attention_heads=self.num_attention_heads, width=self.width,
+                    mlp_ratio=self.mlp_ratio, cross_attention_dim=self.cross_attention_dim,
+                    inflated_layers=list(self.inflated_layers))
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = {k.replace("_orig_mod.", ""): v.detach().to("cpu", torch.float32) for k, v in state_dict.items()}
+        self._host_sd = sd
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        return nn.modules.module._IncompatibleKeys([], [])
+
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs) -> "HipDenoiser":
+        """Reads the PyTorchModelHubMixin layout the reference uses (pipeline.py:180-184):
+        <path>/config.json + <path>/model.safetensors."""
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        fields = ("num_tokens_nominal", "temporal_context_size", "in_channels", "num_layers",
+                  "num_attention_heads", "width", "mlp_ratio", "cross_attention_dim", "inflated_layers")
+        model = cls(**{k: cfg[k] for k in fields if k in cfg}, **kwargs)
+        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
+        return model
+
+    # ---- engine management ---------------------------------------------------------------
+    def _plan(self, T: int) -> FrameShardPlan:
+        if self.process_group is None:
+            return FrameShardPlan(T, 1, 0)
+        return FrameShardPlan(T, dist.get_world_size(self.process_group), dist.get_rank(self.process_group))
+
+    def _ensure_engine(self, B: int, T_local: int, N: int, S: int, plan: FrameShardPlan) -> HipEngine:
+        if self._host_sd is None:
+            raise RuntimeError("HipDenoiser: no weights loaded (load_state_dict / from_pretrained first)")
+        e = self._engine
+        if e is not None and e.device == self.device and e.fits(B, T_local, N, S) and e.world == plan.world:
+            return e
+        if e is not None:
+            e.close()
+        self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
+                                 world=plan.world, rank=plan.rank, attn_defer_log2=self.attn_defer_log2)
+        self._window = None
+        return self._engine
+
+    def bind_window(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int) -> WindowCache:
+        """Build the step-invariant state for one window: RoPE table and cross-attention K/V."""
+        B, T, S, _ = context.shape
+        plan = self._plan(T)
+        e = self._ensure_engine(B, plan.frames_local, n_tokens, S, plan)
+        cos, sin = rope_tables_host(framestep, HEAD_DIM)
+        cos = cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, HEAD_DIM // 2)
+        sin = sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, HEAD_DIM // 2)
+        e.set_context(plan.slice_frames(context), cos, sin)
+        self._generation += 1
+        self._window = WindowCache(self._generation)
+        return self._window
+
+    def forward_host_time(self, hidden_states: torch.Tensor, t_bt: List[float]) -> torch.Tensor:
+        """Forward with the masked per-(b,t) diffusion times already on the host."""
+        B, T, N, _ = hidden_states.shape
+        plan = self._plan(T)
+        e = self._engine
+        if e is None or self._window is None:
+            raise RuntimeError("HipDenoiser: bind_window() must precede forward_host_time()")
+        if plan.world == 1:
+            return e.forward(hidden_states, t_bt)
+        tl = plan.frames_local
+        t_local = [t_bt[b * T + plan.rank * tl + j] for b in range(B) for j in range(tl)]
+        v_local = sharded_forward(e, plan, self.process_group, plan.slice_frames(hidden_states), t_local)
+        return gather_frames(v_local, plan, self.process_group)
+
+    def forward(self, hidden_states: torch.Tensor, context: torch.Tensor, framestep: torch.Tensor,
+                diffusion_time: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                freqs_rot: Optional[WindowCache] = None):
+        B, T, N, _ = hidden_states.shape
+        if not (isinstance(freqs_rot, WindowCache) and self._window is not None
+                and freqs_rot.generation == self._window.generation):
+            freqs_rot = self.bind_window(context, framestep, N)
+        t_bt = masked_time(diffusion_time.detach().float().cpu().tolist(), mask, B, T)
+        return self.forward_host_time(hidden_states, t_bt), freqs_rot

@@ -1,0 +1,181 @@
+"""Kernel-level Python wrappers over the C-ABI (torch tensors in, raw pointers out).
+
+These are thin marshalling helpers: torch provides device memory and the current
+HIP stream, the arithmetic is entirely in libactionmesh_amd.so.  Used by the
+parity tests and by the attention-processor seam (S3).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+HEAD_DIM = 128
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: actionmesh_amd kernels need a device tensor (no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def perm16_index(n: int, device=None) -> torch.Tensor:
+    """position -> key index map of the V^T layout (bit2 <-> bit3 inside each 16-group)."""
+    k = torch.arange(n, device=device)
+    return (k & ~0xC) | ((k & 4) << 1) | ((k & 8) >> 1)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, gelu: bool = False,
+         a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
+         M: Optional[int] = None) -> torch.Tensor:
+    """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
+
+    a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
+    a_map / c_map = (G, group_stride, offset) row maps (G=0: identity)."""
+    _need(a, torch.bfloat16, "a"); _need(w, torch.bfloat16, "w")
+    K1 = a.shape[1]
+    K = w.shape[1]
+    N = w.shape[0]
+    if M is None:
+        M = a.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    _need(out, torch.bfloat16, "out")
+    g = L.AmGemmArgs()
+    g.A1 = a.data_ptr(); g.lda1 = a.stride(0); g.K1 = K1
+    g.A2 = _p(a2); g.lda2 = a2.stride(0) if a2 is not None else 0
+    if a2 is not None:
+        _need(a2, torch.bfloat16, "a2")
+        assert K1 + a2.shape[1] == K
+    else:
+        assert K1 == K
+    g.W = w.data_ptr(); g.ldw = w.stride(0)
+    g.bias = _p(_need(bias, torch.float32, "bias")) if bias is not None else None
+    g.residual = _p(_need(residual, torch.bfloat16, "residual")) if residual is not None else None
+    g.C = out.data_ptr(); g.ldc = out.stride(0)
+    g.M, g.N, g.K = M, N, K
+    g.act = 1 if gelu else 0
+    g.a_G, g.a_gs, g.a_off = a_map
+    g.c_G, g.c_gs, g.c_off = c_map
+    L.check(L.lib().am_gemm_bf16(C.byref(g), _stream()), "am_gemm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need(x, torch.bfloat16, "x"); _need(w, torch.float32, "w"); _need(b, torch.float32, "b")
+    Cdim = x.shape[-1]
+    rows = x.numel() // Cdim
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(L.lib().am_layernorm_bf16(x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                      rows, Cdim, eps, _stream()), "am_layernorm_bf16")
+    return out
+
+
+def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, rows_per_frame: int,
+              w_q: Optional[torch.Tensor] = None, w_k: Optional[torch.Tensor] = None,
+              rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, eps: float = 1e-6,
+              out_q: Optional[torch.Tensor] = None, out_k: Optional[torch.Tensor] = None,
+              out_vt: Optional[torch.Tensor] = None):
+    """Split heads of x (rows, heads*len(kinds)*128), apply qk-RMSNorm (+RoPE), and write the
+    attention operand layouts.  Returns (Q, K, Vt) (None for absent kinds):
+      Q  (nseq, H, sq_pad, 128), K (nseq, H, sk_pad, 128), Vt (nseq, H, 128, sk_pad)."""
+    _need(x, torch.bfloat16, "x")
+    rows = x.shape[0]
+    nseq = rows // seq_len
+    sq_pad, sk_pad = round_up(seq_len, 256), round_up(seq_len, 64)
+    dev = x.device
+    a = L.AmHeadPostArgs()
+    a.X = x.data_ptr(); a.ldx = x.stride(0)
+    a.rows = rows; a.seq_len = seq_len; a.rows_per_frame = rows_per_frame
+    a.heads = heads; a.nparts = len(kinds)
+    for i, k in enumerate(kinds):
+        a.kinds[i] = k
+    a.w_q = _p(w_q); a.w_k = _p(w_k); a.eps = eps
+    if rope is not None:
+        a.rope_cos = _need(rope[0], torch.float32, "rope_cos").data_ptr()
+        a.rope_sin = _need(rope[1], torch.float32, "rope_sin").data_ptr()
+    if 0 in kinds and out_q is None:
+        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+    if 1 in kinds and out_k is None:
+        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+    if 2 in kinds and out_vt is None:
+        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=torch.bfloat16, device=dev)
+    a.out_q = _p(out_q); a.sq_pad = out_q.shape[2] if out_q is not None else 0
+    a.out_k = _p(out_k); a.out_vt = _p(out_vt)
+    a.sk_pad = out_k.shape[2] if out_k is not None else (out_vt.shape[3] if out_vt is not None else 0)
+    L.check(L.lib().am_head_post(C.byref(a), _stream()), "am_head_post")
+    return out_q, out_k, out_vt
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: int,
+              out: Optional[torch.Tensor] = None, nchunks: int = 1, defer_log2: int = 8,
+              scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v on pre-laid-out operands.
+      q (nseq, H, sq_pad, 128); k ([chunks,] nseq, H, sk_pad, 128); vt ([chunks,] nseq, H, 128, sk_pad)
+      -> out (nseq * sq, H * 128)"""
+    _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
+    nseq, H, sq_pad, _ = q.shape
+    sk_pad = k.shape[-2]
+    if out is None:
+        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=torch.bfloat16, device=q.device)
+    a = L.AmAttnArgs()
+    a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = nseq, H, sq, sq_pad, sk, sk_pad
+    a.nchunks = nchunks
+    a.chunk_stride = nseq * H * sk_pad * HEAD_DIM
+    a.ldo = out.stride(0)
+    a.scale = scale if scale is not None else HEAD_DIM ** -0.5
+    a.defer_log2 = defer_log2
+    L.check(L.lib().am_attention_bf16(C.byref(a), _stream()), "am_attention_bf16")
+    return out
+
+
+def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _need(x, torch.float32, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().am_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "am_f32_to_bf16")
+    return y
+
+
+def timestep_sinusoid(t: torch.Tensor, width: int) -> torch.Tensor:
+    _need(t, torch.float32, "t")
+    y = torch.empty((t.numel(), width), dtype=torch.bfloat16, device=t.device)
+    L.check(L.lib().am_timestep_sinusoid(t.data_ptr(), y.data_ptr(), t.numel(), width, _stream()),
+            "am_timestep_sinusoid")
+    return y
+
+
+def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], dt: float,
+              is_additive: bool, unobserved: Optional[Sequence[bool]]) -> None:
+    """In place: latents (T, N, D) fp32 += sign * bf16(dt * cfg(v)); v (n_branches, T, N, D) bf16."""
+    _need(v, torch.bfloat16, "v"); _need(latents, torch.float32, "latents")
+    nb, T, N, D = v.shape
+    sc = (C.c_float * max(1, len(scales)))(*[float(s) for s in scales])
+    un = None
+    if unobserved is not None:
+        un = (C.c_uint8 * T)(*[1 if u else 0 for u in unobserved])
+    L.check(L.lib().am_flow_step(v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
+                                 un, T, N, D, _stream()), "am_flow_step")

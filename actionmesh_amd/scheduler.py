@@ -1,0 +1,159 @@
+"""HipSchedulerFlow / ClassifierFreeGuidance: drop-ins for
+actionmesh.scheduler.scheduler.SchedulerFlow (reference scheduler.py:23-295) and
+actionmesh.scheduler.guidance.ClassifierFreeGuidance (guidance.py:13-118).
+
+Same dataclass fields and method signatures, so a Hydra overlay can swap the
+`_target_`s (actionmesh_amd/configs/actionmesh_mi355x.yaml).  `denoise` drives the
+HIP denoiser: the CFG batch, context K/V cache and RoPE table are built once per
+window; each step is one C-ABI forward plus one fused CFG+Euler kernel.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .denoiser import HipDenoiser
+
+
+@dataclass(eq=False)
+class ClassifierFreeGuidance:
+    """Conditioning order is [image-conditioning | latent0-conditioning] (guidance.py:15-17)."""
+
+    inference_enabled: bool = True
+    guidance_at_inference: list = field(default_factory=lambda: [[0, 0], [0, 1], [1, 1]])
+    guidance_scales: list = field(default_factory=lambda: [1.0, 1.0])
+
+    def __post_init__(self):
+        assert len(self.guidance_at_inference) == len(self.guidance_scales) + 1
+
+    def get_unobserved_mask(self, mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if mask is None else mask == 0
+
+    def branches(self) -> List[List[int]]:
+        return [list(g) for g in self.guidance_at_inference] if self.inference_enabled else [[1, 1]]
+
+    def cfg_at_inference(self, latent, context, mask, framestep):
+        """guidance.py:38-93: one batch row per guidance branch; a 0 flag zeroes that conditioning."""
+        if not self.inference_enabled:
+            return latent, context, mask, framestep
+        n = len(self.guidance_at_inference)
+        latent = torch.cat([latent] * n)
+        framestep = torch.cat([framestep] * n) if framestep is not None else None
+        ctxs, masks = [], []
+        for g in self.guidance_at_inference:
+            g = list(g)
+            if g not in ([1, 1], [0, 1], [1, 0], [0, 0]):
+                raise Exception(f"Unknown guidance: {g}")
+            ctxs.append(context if g[0] == 1 else torch.zeros_like(context))
+            if mask is not None:
+                masks.append(mask if g[1] == 1 else torch.zeros_like(mask))
+        return latent, torch.cat(ctxs, dim=0), (torch.cat(masks, dim=0) if mask is not None else None), framestep
+
+    def aggregate_cfg(self, aggregated: torch.Tensor) -> torch.Tensor:
+        """guidance.py:95-118 (torch glue; the fused device version is ops.flow_step)."""
+        if not self.inference_enabled:
+            return aggregated
+        outs = aggregated.chunk(len(self.guidance_at_inference), dim=0)
+        assert len(outs) == len(self.guidance_at_inference)
+        output = outs[0]
+        for i in range(len(self.guidance_at_inference) - 1):
+            output += self.guidance_scales[i] * (outs[i + 1] - outs[i])
+        return output
+
+
+@dataclass(eq=False)
+class HipSchedulerFlow:
+    num_inference_steps: int
+    num_train_timesteps: int = 1000
+    shift: float = 3.0
+    is_additive: bool = False
+    split_cfg_batch: bool = False   # accepted for config parity; the HIP path always batches CFG
+
+    def get_schedule(self):
+        """scheduler.py:43-56."""
+        timesteps = self._compute_timesteps(self.num_inference_steps + 1, self.num_train_timesteps, self.shift)
+        distances = (timesteps[:-1] - timesteps[1:]) / self.num_train_timesteps
+        return timesteps, distances
+
+    @staticmethod
+    def _compute_timesteps(num_inference_steps: int, num_train_timesteps: int = 1000,
+                           shift: float = 1.0) -> torch.Tensor:
+        """scheduler.py:59-98: shifted-sigma schedule, fp64 numpy -> fp32."""
+        n = num_train_timesteps
+        full = (np.linspace(1, n, n) / n)[::-1]
+        full_shifted = shift * full / (1 + (shift - 1) * full)
+        t = np.linspace(full_shifted[0] * n, full_shifted[-1] * n, num_inference_steps)
+        s = t / n
+        s = shift * s / (1 + (shift - 1) * s)
+        return torch.from_numpy((s * n).astype(np.float32))
+
+    def get_noise(self, latent_shape, batch_size: int, n_timesteps: int, device,
+                  generator: Optional[torch.Generator] = None, corr_noise: float = 0.0) -> torch.Tensor:
+        """scheduler.py:100-137: two draws in this order (same, then independent)."""
+        assert 0 <= corr_noise <= 1.0
+        same = torch.randn([batch_size, 1] + list(latent_shape), generator=generator,
+                           device=device).repeat(1, n_timesteps, 1, 1)
+        indep = torch.randn([batch_size, n_timesteps] + list(latent_shape), generator=generator, device=device)
+        return math.sqrt(corr_noise) * same + math.sqrt(1 - corr_noise) * indep
+
+    def _flow_sample(self, diffusion_model, cf_guidance, init_latent, context, device="cuda:0",
+                     disable_prog: bool = True, mask=None, framestep=None):
+        """scheduler.py:172-250 on the HIP path.  Yields (latents, t) like the reference (the same
+        tensor object every step; clone to record)."""
+        if not isinstance(diffusion_model, HipDenoiser):
+            raise TypeError("HipSchedulerFlow drives a HipDenoiser; got "
+                            f"{type(diffusion_model).__name__} (there is no torch fallback path)")
+        if init_latent.dim() != 4 or init_latent.shape[0] != 1:
+            raise ValueError("HipSchedulerFlow expects init_latent of shape (1, T, N, D) as the pipeline passes it")
+        dev = diffusion_model.device
+        latents = init_latent.to(dev, torch.float32)
+        if not latents.is_contiguous():
+            latents = latents.contiguous()
+        _, T, N, D = latents.shape
+        branches = cf_guidance.branches()
+        nb = len(branches)
+        scales = [float(s) for s in cf_guidance.guidance_scales] if cf_guidance.inference_enabled else []
+        ctx = context.to(dev, torch.float32)
+        ctx_b = torch.cat([ctx if g[0] == 1 else torch.zeros_like(ctx) for g in branches], dim=0)
+        if framestep is None:
+            framestep = torch.arange(T, dtype=torch.float32)[None]
+        fs_b = torch.cat([framestep.detach().float().cpu()] * nb, dim=0)
+        mask_host = None if mask is None else mask.detach().float().cpu().reshape(-1).tolist()
+        unobserved = None if mask_host is None else [m == 0 for m in mask_host]
+        if unobserved is not None and not any(unobserved):
+            raise AssertionError("No unobserved frames found")           # scheduler.py:245
+        keep = [[(1.0 - m) if g[1] == 1 else 1.0 for m in mask_host] if mask_host is not None else [1.0] * T
+                for g in branches]
+
+        timesteps, distances = self.get_schedule()
+        diffusion_model.bind_window(ctx_b, fs_b, N)
+        it = range(self.num_inference_steps)
+        if not disable_prog:
+            from tqdm import tqdm
+            it = tqdm(it, desc="Temporal 3D Denoising (Stage I)", leave=True)
+        for i in it:
+            t = float(timesteps[i])
+            t_bt = [t * k for row in keep for k in row]                  # temporal_denoiser.py:209-212
+            x_in = latents.expand(nb, T, N, D).contiguous()
+            v = diffusion_model.forward_host_time(x_in, t_bt)
+            ops.flow_step(v, latents[0], scales, float(distances[i]), self.is_additive, unobserved)
+            yield latents, timesteps[i]
+
+    @torch.no_grad()
+    def denoise(self, diffusion_model, cf_guidance, init_latent, context, device="cuda:0",
+                disable_prog: bool = True, mask=None, framestep=None,
+                step_callback: Optional[Callable[[int, int], None]] = None):
+        """scheduler.py:252-295."""
+        latents = None
+        total = self.num_inference_steps
+        for step_idx, (sample, _t) in enumerate(self._flow_sample(
+                diffusion_model, cf_guidance, init_latent, context, device, disable_prog, mask, framestep)):
+            latents = sample
+            if step_callback is not None:
+                step_callback(step_idx + 1, total)
+        return latents

@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py - denoise-steps/sec of the Stage-I hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one CFG-batched (B=2) denoiser forward + CFG recombination + Euler update
+(BASELINE.json metric).  Workload = BASELINE.json configs[1] shape in its synthetic form
+(SURVEY.md 8(d) "headline"): T=16 frames x N=4096 latent tokens, width 1024 (8 heads x 128),
+21 layers all inflated, S=257 context tokens, random-init weights, seeded N(0,1) inputs already
+resident in HBM.  N>1: frames are sharded across ranks (strong scaling: the problem is fixed),
+one K/V all-gather per layer over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  "roofline":     dominant kernel (inflated self-attention) vs the dense bf16 MFMA peak, timed
+                  live with HIP events on the launch stream,
+  "cpu_baseline": the CPU oracle (a port of the reference path; oracle/denoiser_oracle.py)
+                  timed on this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+SHAPES = {
+    # name: (T, N, width, heads, layers, S, Dc, Din)
+    "headline": (16, 4096, 1024, 8, 21, 257, 1024, 64),     # "16f x 4096tok x 1024-dim"
+    "nominal": (16, 2048, 2048, 16, 21, 257, 1024, 64),     # the shipped model (actionmesh.yaml:33-43)
+    "small": (4, 512, 256, 2, 5, 17, 64, 64),               # plumbing check
+}
+
+
+def random_state_dict(hp, seed=0):
+    """Random-init weights of the reference architecture (nn.Linear-scale uniform; norms = 1/0)."""
+    C, F_, Dc, Din, NL = hp["width"], int(hp["width"] * hp["mlp_ratio"]), hp["cross_attention_dim"], hp["in_channels"], hp["num_layers"]
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(n_out, n_in, bias=True, name=""):
+        b = n_in ** -0.5
+        out = {name + ".weight": (torch.rand((n_out, n_in), generator=g) * 2 - 1) * b}
+        if bias:
+            out[name + ".bias"] = (torch.rand((n_out,), generator=g) * 2 - 1) * b
+        return out
+
+    def norm(n, name, bias=True):
+        out = {name + ".weight": torch.ones(n)}
+        if bias:
+            out[name + ".bias"] = torch.zeros(n)
+        return out
+
+    sd = {}
+    sd.update(lin(4 * C, C, name="time_proj.linear_1")); sd.update(lin(C, 4 * C, name="time_proj.linear_2"))
+    sd.update(lin(C, Din, name="proj_in"))
+    for i in range(NL):
+        p = f"blocks.{i}."
+        sd.update(norm(C, p + "norm_s_attn")); sd.update(norm(C, p + "norm_x_attn")); sd.update(norm(C, p + "norm_ff"))
+        for a in ("s_attn", "x_attn"):
+            sd.update(norm(128, p + a + ".norm_q", bias=False)); sd.update(norm(128, p + a + ".norm_k", bias=False))
+            sd.update(lin(C, C, bias=False, name=p + a + ".to_q"))
+            kin = C if a == "s_attn" else Dc
+            sd.update(lin(C, kin, bias=False, name=p + a + ".to_k")); sd.update(lin(C, kin, bias=False, name=p + a + ".to_v"))
+            sd.update(lin(C, C, name=p + a + ".to_out.0"))
+        sd.update(lin(F_, C, name=p + "ff.net.0.proj")); sd.update(lin(C, F_, name=p + "ff.net.2"))
+        if i > NL // 2:
+            sd.update(norm(C, p + "norm_skip")); sd.update(lin(C, 2 * C, name=p + "linear_skip"))
+    sd.update(norm(C, "norm_out")); sd.update(lin(Din, C, name="proj_out"))
+    return sd
+
+
+def attention_roofline(T, N, H, dev, world=1, reps=3):
+    """Time the dominant kernel (inflated self-attention, both CFG samples) with HIP events on the
+    launch stream.  One launch = one layer on one rank: this rank's T/world frames of queries
+    against all T frames of keys; algorithmic flops per launch = 4 * (T*L/world) * (T*L) * (H*128) * B
+    (SURVEY.md 8(d))."""
+    from actionmesh_amd import ops
+    B, L = 2, N + 1
+    Sq = (T // world) * L            # local query rows == keys per chunk
+    sq_pad, sk_pad = ops.round_up(Sq, 256), ops.round_up(Sq, 64)
+    g = torch.Generator(device=dev).manual_seed(0)
+    Q = torch.randn((B, H, sq_pad, 128), device=dev, generator=g).to(torch.bfloat16)
+    K = torch.randn((world, B, H, sk_pad, 128), device=dev, generator=g).to(torch.bfloat16)
+    Vt = torch.randn((world, B, H, 128, sk_pad), device=dev, generator=g).to(torch.bfloat16)
+    out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=dev)
+    ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=world)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=world)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / reps
+    flops = 4.0 * Sq * (Sq * world) * (H * 128) * B
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel (inflated self-attention, 1 launch = 1 layer)",
+            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launch_ms": round(sec * 1e3, 3), "flops_per_launch": flops}
+
+
+def cpu_baseline(hp, sd, step_flops_full, S):
+    """Reference CPU path (fp32 - the reference's cuda autocast is inert on CPU) as restated by the
+    oracle, timed on a bounded sample and scaled by algorithmic flops to the full workload."""
+    from oracle import denoiser_oracle as O   # checker / baseline only, never on the product path
+    cfg = O.OracleConfig(in_channels=hp["in_channels"], num_layers=hp["num_layers"],
+                         num_attention_heads=hp["num_attention_heads"], width=hp["width"],
+                         mlp_ratio=hp["mlp_ratio"], cross_attention_dim=hp["cross_attention_dim"],
+                         inflated_layers=tuple(hp["inflated_layers"]))
+    Ts, Ns = 8, 512
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, Ts, Ns, hp["in_channels"], generator=g)
+    c = torch.randn(2, Ts, S, hp["cross_attention_dim"], generator=g)
+    c[0] = 0
+    fs = torch.arange(Ts, dtype=torch.float32)[None].repeat(2, 1)
+    m = torch.zeros(2, Ts); m[:, 0] = 1
+    t = torch.tensor([700.0, 700.0])
+    fl = O.step_flops(2, Ts, Ns, cfg, S)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.denoiser_forward(sd, cfg, x, c, fs, t, m, "fp32")
+        sec = time.perf_counter() - t0
+    rate = fl / sec
+    return {"value": rate / step_flops_full, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward at B=2,T={Ts},N={Ns} ({fl:.3e} flop in {sec:.1f} s = "
+                      f"{rate / 1e12:.3f} TFLOP/s), scaled by algorithmic flops to the full step "
+                      f"({step_flops_full:.3e} flop) - an extrapolation, the full CPU step would take "
+                      f"~{step_flops_full / rate / 60:.0f} min"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", default="headline", choices=list(SHAPES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    T, N, C, H, NL, S, Dc, Din = SHAPES[args.shape]
+    hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0,
+              cross_attention_dim=Dc, inflated_layers=list(range(NL)))
+    sd = random_state_dict(hp, seed=0)
+    model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, **hp)
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+
+    g = torch.Generator().manual_seed(0)
+    init_latent = torch.randn(1, T, N, Din, generator=g).to(dev)
+    context = torch.randn(1, T, S, Dc, generator=g).to(dev)
+    mask = torch.zeros(1, T); mask[0, 0] = 1.0
+    framestep = torch.arange(T, dtype=torch.float32)[None]
+    total = args.warmup + args.steps
+    sched = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    loop = sched._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
+                              framestep=framestep)
+    for _ in range(args.warmup):
+        next(loop)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next(loop)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert bool(torch.isfinite(init_latent).all()), "non-finite latents"
+
+    step_flops = model._engine.step_flops(2, T, N, S)
+    steps_per_s = args.steps / elapsed
+    result = {
+        "metric": "denoise-steps/sec (16f x 4096tok)", "value": round(steps_per_s, 4),
+        "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
+                               f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
+                               "random-init weights, seeded N(0,1) latents/context resident in HBM",
+                   "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                   "step_flops": step_flops},
+        "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
+        "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+    }
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = attention_roofline(T, N, H, dev, world)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del model
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

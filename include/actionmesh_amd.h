@@ -1,0 +1,207 @@
+/*
+ * actionmesh_amd.h - C ABI of libactionmesh_amd.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ONE hot path of facebookresearch/actionmesh: the Stage-I
+ * temporal-3D flow-matching denoise loop.  The reference has no FFI (it is pure
+ * Python); its plug-in seams for this path are:
+ *
+ *   S1  actionmesh/scheduler/scheduler.py:252-295   SchedulerFlow.denoise
+ *   S2  actionmesh/model/temporal_denoiser.py:151-249 ActionMeshDenoiser.forward
+ *   S3  actionmesh/model/utils/attention_processor.py:36-168 AttentionProcessor.__call__
+ *
+ * Each entry point below names the reference interface it replaces.  The
+ * reference-side binding (a ctypes stub) is shown in INTEGRATION.md; the
+ * in-tree binding is actionmesh_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.
+ *   - every `*_dev` pointer is device memory valid on `stream` (a hipStream_t
+ *     passed as void*; NULL = the null stream).  Pointers are borrowed for the
+ *     duration of the call; nothing synchronises the device unless stated.
+ *   - bf16 tensors are raw uint16 payloads, row-major.
+ *   - return 0 on success, negative am_status otherwise; am_last_error() gives
+ *     the message of the calling thread's last failure.
+ *   - one handle per device per rank; a handle is not thread-safe (the
+ *     reference drives this path from a single Python thread).
+ */
+#ifndef ACTIONMESH_AMD_H
+#define ACTIONMESH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  AM_OK = 0,
+  AM_ERR_INVALID = -1,   /* bad argument / shape */
+  AM_ERR_HIP = -2,       /* a HIP runtime call failed */
+  AM_ERR_STATE = -3,     /* call sequence violated (e.g. forward before weights) */
+  AM_ERR_NOTFOUND = -4   /* unknown weight name */
+} am_status;
+
+const char* am_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int am_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Model-level API                                                            */
+/* ------------------------------------------------------------------------ */
+
+/* Hyper-parameters of ActionMeshDenoiser (temporal_denoiser.py:29-48) plus the
+ * static problem bounds the workspace is sized for. head_dim must be 128. */
+typedef struct {
+  int32_t in_channels;          /* Din (64) */
+  int32_t num_layers;           /* NL (21) */
+  int32_t num_heads;            /* H */
+  int32_t width;                /* C = H*128 */
+  int32_t ff_inner;             /* F = int(C*mlp_ratio) */
+  int32_t cross_dim;            /* Dc (1024) */
+  uint32_t inflated_mask_lo;    /* bit i set => layer i uses inflated (joint T*L) self-attention */
+  uint32_t inflated_mask_hi;    /* layers 32..63 */
+  int32_t max_batch;            /* CFG batch B (2) */
+  int32_t max_frames_local;     /* frames owned by this rank (T / world) */
+  int32_t max_tokens;           /* N latent tokens per frame */
+  int32_t max_ctx_tokens;       /* S context tokens per frame */
+  int32_t world_size;           /* frame-shard degree P (1 = single GPU) */
+  int32_t rank;                 /* this rank's shard index */
+  int32_t attn_defer_log2;      /* online-softmax deferred-rescale threshold (log2 units); 0 = always rescale */
+  int32_t reserved[7];
+} am_config;
+
+typedef struct am_model* am_handle;
+
+int am_create(const am_config* cfg, am_handle* out);
+int am_destroy(am_handle h);
+
+/* Replaces PyTorchModelHubMixin.from_pretrained / load_state_dict for
+ * ActionMeshDenoiser (pipeline.py:180-184).  `name` is a reference state-dict
+ * key; `host_f32` is the fp32 tensor, row-major, `numel`
+ * elements.  The library converts / fuses (q|k|v concatenated) and owns its copy. */
+int am_load_weight(am_handle h, const char* name, const float* host_f32, size_t numel);
+/* Number of reference state-dict keys still missing (0 = ready). */
+int am_weights_missing(am_handle h);
+
+/* Step-invariant conditioning for one window (replaces the per-step
+ * to_k/to_v(context) of attention_processor.py:102-103 with a cache; and
+ * precompute_freqs_rot, temporal_denoiser.py:114-149).
+ *   ctx_dev       fp32 (B, T_local, S, Dc) device
+ *   rope_cos/sin  fp32 host (B*T_local, 64): cos/sin of position*inv_freq per frame
+ */
+int am_set_context(am_handle h, const float* ctx_dev, int B, int T_local, int S,
+                   const float* rope_cos_host, const float* rope_sin_host, void* stream);
+
+/* ActionMeshDenoiser.forward (temporal_denoiser.py:151-249), CFG-batched.
+ *   x_dev     fp32 (B, T_local, N, Din)
+ *   t_bt_host fp32 (B*T_local): per-(b,t) diffusion time AFTER the mask
+ *             (temporal_denoiser.py:209-212)
+ *   v_out_dev bf16 (B, T_local, N, Din)
+ * Single-rank convenience = begin + for each layer {pre, post} + end. */
+int am_denoise_forward(am_handle h, const float* x_dev, const float* t_bt_host,
+                       int B, int T_local, int N, uint16_t* v_out_dev, void* stream);
+
+/* The same forward, split at the temporal-attention boundary so the host can
+ * run the K/V all-gather (RCCL) between `pre` and `post` of an inflated layer. */
+int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host,
+                     int B, int T_local, int N, void* stream);
+int am_layer_pre_attn(am_handle h, int layer, void* stream);   /* skip+LN+QKV+qk-norm+RoPE -> local K/V shard */
+int am_layer_post_attn(am_handle h, int layer, void* stream);  /* self-attn .. FFN */
+int am_forward_end(am_handle h, uint16_t* v_out_dev, void* stream);
+
+/* K / V^T gather buffers for inflated self-attention, laid out
+ * [world][B][H][sk_pad][128] (K) and [world][B][H][128][sk_pad] (V^T); this
+ * rank writes chunk `rank`.  By default the library owns them; a multi-GPU
+ * host binds its own (torch-allocated) buffers so it can all-gather in place. */
+int am_kv_chunk_elems(am_handle h, size_t* elems_per_chunk);
+int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev);
+
+/* ClassifierFreeGuidance.aggregate_cfg (guidance.py:95-118) + the Euler flow
+ * step and masked write of SchedulerFlow._flow_sample (scheduler.py:238-248):
+ *   v = v_0 + sum_i scale_i (v_{i+1} - v_i)   (bf16 arithmetic, as the reference)
+ *   latents[f] += sign * bf16(dt * v[f])  for frames with unobserved[f] != 0
+ *   latents_dev fp32 (T_local, N, Din); v_dev bf16 (n_branches, T_local, N, Din) */
+int am_flow_step(const uint16_t* v_dev, float* latents_dev, int n_branches,
+                 const float* scales_host, float dt, int is_additive,
+                 const uint8_t* unobserved_host, int T_local, int N, int Din, void* stream);
+
+/* algorithmic flops of one forward (SURVEY.md 8(d) formula) for the bound shape */
+double am_step_flops(am_handle h, int B, int T_total, int N, int S);
+
+/* ------------------------------------------------------------------------ */
+/* Kernel-level API (stateless).  These are what seam S3 binds, and what the   */
+/* parity tests call one by one.                                               */
+/* ------------------------------------------------------------------------ */
+
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) + residual, bf16 in/out, fp32 accumulate.
+ * Replaces nn.Linear (+ GELU of diffusers FeedForward, + the block's residual add)
+ * at block.py:131-152 / attention_processor.py:92-103,147.
+ *   A may be split in two column blocks (A1: first K1 cols, A2: rest) = the
+ *   torch.cat([skip, h]) of block.py:131 without materialising it.
+ *   Row maps: physical_row(r) = (r / G) * gs + off + r % G  (G = 0 => identity).
+ *   residual uses C's row map and leading dimension; may alias C.            */
+typedef struct {
+  const uint16_t* A1; int32_t lda1; int32_t K1;
+  const uint16_t* A2; int32_t lda2;
+  const uint16_t* W;  int32_t ldw;
+  const float* bias;
+  const uint16_t* residual;
+  uint16_t* C; int32_t ldc;
+  int32_t M, N, K;
+  int32_t act;                 /* 0 none, 1 exact-erf GELU */
+  int32_t a_G, a_gs, a_off;
+  int32_t c_G, c_gs, c_off;
+} am_gemm_args;
+int am_gemm_bf16(const am_gemm_args* args, void* stream);
+
+/* FP32LayerNorm / nn.LayerNorm (block.py:64,83,98,107; temporal_denoiser.py:107):
+ * y = (x-mean)/sqrt(var+eps)*w+b, fp32 statistics, bf16 in/out. C % 8 == 0, C <= 4096. */
+int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,
+                      int64_t rows, int C, float eps, void* stream);
+
+/* Head split + qk RMSNorm + RoPE + attention operand layout
+ * (attention_processor.py:106-130).
+ *   X [rows][ldx] bf16; head h, part p at columns (h*nparts + p)*128.
+ *   rows are grouped in sequences of `seq_len` rows; each sequence is
+ *   `seq_len / rows_per_frame` frames; the RoPE row of a token is its global
+ *   frame index  (row / rows_per_frame).
+ *   part kinds: 0 = Q-like (RMSNorm w0, optional RoPE) -> out0 [nseq][H][s0_pad][128]
+ *               1 = K-like (RMSNorm w1, optional RoPE) -> out1 [nseq][H][s1_pad][128]
+ *               2 = V      (copy)                      -> out2 [nseq][H][128][s1_pad], keys
+ *                   permuted inside each group of 16 (bit2<->bit3) for the PV MFMA.  */
+typedef struct {
+  const uint16_t* X; int32_t ldx;
+  int64_t rows; int32_t seq_len; int32_t rows_per_frame;
+  int32_t heads; int32_t nparts; int32_t kinds[3];
+  const float* w_q; const float* w_k; float eps;
+  const float* rope_cos; const float* rope_sin;   /* [frames][64] or NULL */
+  uint16_t* out_q; int32_t sq_pad;
+  uint16_t* out_k; uint16_t* out_vt; int32_t sk_pad;
+} am_headpost_args;
+int am_head_post(const am_headpost_args* args, void* stream);
+
+/* F.scaled_dot_product_attention, non-causal, head_dim 128
+ * (attention_processor.py:133-139).  Online-softmax flash kernel on bf16 MFMA.
+ *   Q  [nseq][H][sq_pad][128]; K [chunks][nseq][H][sk_pad][128];
+ *   Vt [chunks][nseq][H][128][sk_pad] (permuted as am_head_post writes it);
+ *   O  [nseq*sq][ldo] at column h*128 (heads concatenated, token-major).
+ *   Each chunk holds `sk` valid keys.  sq_pad % 256 == 0, sk_pad % 64 == 0. */
+typedef struct {
+  const uint16_t* Q; const uint16_t* K; const uint16_t* Vt; uint16_t* O;
+  int32_t nseq, heads, sq, sq_pad, sk, sk_pad, nchunks;
+  int64_t chunk_stride;        /* elements between consecutive chunks of K (and of Vt) */
+  int32_t ldo; float scale; int32_t defer_log2;
+} am_attn_args;
+int am_attention_bf16(const am_attn_args* args, void* stream);
+
+/* small fused elementwise ops */
+int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream);
+int am_bf16_to_f32(const uint16_t* x, float* y, size_t n, void* stream);
+/* diffusers Timesteps(flip_sin_to_cos=False, shift=0): [sin(t f) | cos(t f)] -> bf16 (rows, C) */
+int am_timestep_sinusoid(const float* t_dev, uint16_t* out, int rows, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACTIONMESH_AMD_H */

@@ -1,0 +1,136 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, and the host-side
+mirror of the reference interface (schedule, guidance, RoPE table, masked time, shard plan)
+matches the reference's known answers.  No compute calls into the HIP library here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import actionmesh_amd as A
+from actionmesh_amd import _lib, denoiser, scheduler
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "actionmesh_amd.h")).read()
+    declared = set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", header))
+    declared -= {"am_status"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()            # raises if the .so is missing / lacks a symbol / ABI mismatch
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.am_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """ctypes mirrors vs the C header, measured by compiling a probe with gcc against include/."""
+    import subprocess
+    structs = {"am_config": _lib.AmConfig, "am_gemm_args": _lib.AmGemmArgs,
+               "am_headpost_args": _lib.AmHeadPostArgs, "am_attn_args": _lib.AmAttnArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "actionmesh_amd.h"', 'int main(void){']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0;}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = dict(l.split() for l in out if l)
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _t in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device (error text via am_last_error)."""
+    lib = _lib.lib()
+    assert lib.am_gemm_bf16(None, None) != 0
+    assert b"null" in lib.am_last_error()
+    g = _lib.AmGemmArgs()
+    g.M, g.N, g.K = 4, 8, 60
+    assert lib.am_gemm_bf16(ctypes.byref(g), None) != 0
+    assert b"multiple of 64" in lib.am_last_error()
+    a = _lib.AmAttnArgs()
+    assert lib.am_attention_bf16(ctypes.byref(a), None) != 0
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "x")
+
+
+def test_no_cpu_fallback():
+    m = A.HipDenoiser(num_layers=1, num_attention_heads=2, width=256, cross_attention_dim=64)
+    m.load_state_dict({})
+    with pytest.raises(RuntimeError):       # CPU device -> refused, not silently computed in torch
+        m.forward(torch.zeros(2, 2, 4, 64), torch.zeros(2, 2, 3, 64), torch.zeros(2, 2), torch.zeros(2))
+    with pytest.raises(TypeError):
+        A.HipSchedulerFlow(num_inference_steps=1).denoise(torch.nn.Identity(), A.ClassifierFreeGuidance(),
+                                                          torch.zeros(1, 2, 4, 64), torch.zeros(1, 2, 3, 64))
+
+
+def test_schedule_kats(golden_dir):
+    k = np.load(os.path.join(golden_dir, "kats.npz"))
+    for n in (10, 15, 30, 50):
+        t, d = A.HipSchedulerFlow(num_inference_steps=n, shift=3.0).get_schedule()
+        assert np.array_equal(t.numpy(), k[f"sched_t_{n}"])
+        assert np.array_equal(d.numpy(), k[f"sched_d_{n}"])
+    s = A.HipSchedulerFlow(num_inference_steps=1)
+    n = s.get_noise([8, 4], 1, 3, "cpu", torch.Generator().manual_seed(7))
+    assert np.array_equal(n.numpy(), k["noise_seed7_small"])       # draw order: same, then independent
+
+
+def test_guidance_matches_reference_kats(golden_dir):
+    k = np.load(os.path.join(golden_dir, "kats.npz"))
+    c = A.ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    assert np.allclose(c.aggregate_cfg(torch.tensor([[1.0], [2.0]])).numpy(), k["cfg_aggregate_1_2"])
+    lat, ctx, m, f = c.cfg_at_inference(torch.ones(1, 2, 3, 4), torch.ones(1, 2, 5, 6), torch.tensor([[1.0, 0.0]]),
+                                        torch.tensor([[0.0, 1.0]]))
+    assert lat.shape[0] == 2 and bool((ctx[0] == 0).all()) and bool((ctx[1] == 1).all())
+    assert torch.equal(m, torch.tensor([[1.0, 0.0], [1.0, 0.0]])) and f.shape == (2, 2)
+    assert c.branches() == [[0, 1], [1, 1]]
+    assert A.ClassifierFreeGuidance(False, [[0, 1], [1, 1]], [7.5]).branches() == [[1, 1]]
+    with pytest.raises(AssertionError):
+        A.ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [1.0, 2.0])
+
+
+def test_rope_host_table_matches_reference_kat(golden_dir):
+    k = np.load(os.path.join(golden_dir, "kats.npz"))
+    cos, sin = denoiser.rope_tables_host(torch.arange(16.0)[None] + 5.0, 128)   # centred: +5 cancels
+    assert cos.shape == (16, 64)
+    assert np.allclose(cos.numpy(), k["rope_cos_128_16"][:, ::2], atol=1e-6)
+    assert np.allclose(sin.numpy(), k["rope_sin_128_16"][:, ::2], atol=1e-6)
+
+
+def test_masked_time_follows_reference_ordering():
+    # temporal_denoiser.py:209-212: repeat(T) is b-fastest, the merged mask is (b t)
+    t = denoiser.masked_time([700.0, 700.0], torch.tensor([[1.0, 0.0, 0.0], [1.0, 0.0, 0.0]]), 2, 3)
+    assert t == [0.0, 700.0, 700.0, 0.0, 700.0, 700.0]
+    t = denoiser.masked_time([1.0, 2.0], None, 2, 2)
+    assert t == [1.0, 2.0, 1.0, 2.0]
+
+
+def test_frame_shard_plan():
+    p = A.FrameShardPlan(16, 4, 2)
+    assert p.frames_local == 4 and p.frame_slice == slice(8, 12)
+    x = torch.arange(2 * 16 * 3).view(2, 16, 3)
+    assert torch.equal(p.slice_frames(x), x[:, 8:12])
+    with pytest.raises(ValueError):
+        A.FrameShardPlan(16, 3, 0)
+    with pytest.raises(ValueError):
+        A.FrameShardPlan(16, 4, 4)
+
+
+def test_perm16_is_an_involution_matching_the_mfma_layout():
+    from actionmesh_amd import ops
+    idx = ops.perm16_index(64)
+    assert torch.equal(idx[idx], torch.arange(64))
+    # k-slot (hi, j) of the P.V MFMA B operand carries key (j&3) + 8*(j>>2) + 4*hi (32x32 C/D layout)
+    for hi in range(2):
+        for j in range(8):
+            assert int(idx[hi * 8 + j]) == (j & 3) + 8 * (j >> 2) + 4 * hi

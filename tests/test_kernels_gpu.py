@@ -1,0 +1,305 @@
+"""Per-kernel parity tests (GPU): every HIP kernel against a plain PyTorch fp32 statement of
+the same op, called through the C-ABI.  Inputs are asymmetric random data so that operand /
+output transposes are detected."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from actionmesh_amd import _lib
+    _lib.lib()   # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _randn(shape, seed, dev, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def _close(out, ref, ulps=2.0, atol=0.0, what=""):
+    """bf16 result within `ulps` bf16 ulps of the fp32 reference (relative 2^-8 each) + atol."""
+    out = out.float()
+    tol = ulps * (2.0 ** -8) * ref.abs() + atol
+    bad = (out - ref).abs() > tol
+    assert not bool(bad.any()), (
+        f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max abs err "
+        f"{float((out - ref).abs().max()):.4e}, ref max {float(ref.abs().max()):.3e}")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 384, 256), (128, 64, 64), (37, 128, 64),
+                                   (4097, 1024, 1024), (2500, 3072, 512)])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "bias_res"])
+def test_gemm(dev, M, N, K, mode):
+    from actionmesh_amd import ops
+    a = _randn((M, K), 1, dev).to(torch.bfloat16)
+    w = _randn((N, K), 2, dev, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+    bias = rb(_randn((N,), 3, dev, 0.5)) if mode != "plain" else None
+    res = _randn((M, N), 4, dev).to(torch.bfloat16) if mode == "bias_res" else None
+    out = ops.gemm(a, w, bias=bias, residual=res, gelu=(mode == "bias_gelu"))
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T
+    if bias is not None:
+        ref = ref + bias
+    ref = rb(ref)
+    if mode == "bias_gelu":
+        ref = rb(F.gelu(ref))
+    if res is not None:
+        ref = ref + res.float()
+    _close(out, ref, ulps=2.0, atol=2e-3 * math.sqrt(K / 64), what=f"gemm {M}x{N}x{K} {mode}")
+
+
+def test_gemm_split_a_and_row_maps(dev):
+    """cat([skip, h]) @ W^T without materialising the cat (block.py:131-132) and the two row
+    maps used for proj_in / time token / proj_out (temporal_denoiser.py:206,217,240-242)."""
+    from actionmesh_amd import ops
+    M, N, K1, K2 = 517, 256, 128, 192
+    a1 = _randn((M, K1), 1, dev).to(torch.bfloat16)
+    a2 = _randn((M, K2), 2, dev).to(torch.bfloat16)
+    w = _randn((N, K1 + K2), 3, dev, 0.05).to(torch.bfloat16)
+    bias = rb(_randn((N,), 4, dev, 0.5))
+    out = ops.gemm(a1, w, bias=bias, a2=a2)
+    ref = rb(torch.cat([a1, a2], 1).float() @ w.float().T + bias)
+    _close(out, ref, atol=4e-3, what="split-A gemm")
+
+    # c_map: logical row r -> frame r//G, physical row frame*gs + off + r%G
+    frames, G, L = 5, 48, 49
+    a = _randn((frames * G, 64), 5, dev).to(torch.bfloat16)
+    w = _randn((256, 64), 6, dev, 0.1).to(torch.bfloat16)
+    dst = torch.full((frames * L, 256), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, out=dst, c_map=(G, L, 1))
+    ref = rb(a.float() @ w.float().T).view(frames, G, 256)
+    got = dst.view(frames, L, 256)
+    _close(got[:, 1:], ref, atol=2e-3, what="c_map rows")
+    assert bool((got[:, 0] == 7.0).all()), "row 0 of every frame must be untouched"
+    # a_map: read rows 1..G of every frame
+    src = _randn((frames * L, 128), 8, dev).to(torch.bfloat16)
+    w2 = _randn((64, 128), 9, dev, 0.1).to(torch.bfloat16)
+    out2 = ops.gemm(src, w2, a_map=(G, L, 1), M=frames * G)
+    ref2 = rb(src.view(frames, L, 128)[:, 1:].reshape(-1, 128).float() @ w2.float().T)
+    _close(out2, ref2, atol=2e-3, what="a_map rows")
+
+
+def test_gemm_in_place_residual(dev):
+    from actionmesh_amd import ops
+    M, N, K = 700, 256, 256
+    a = _randn((M, K), 1, dev).to(torch.bfloat16)
+    w = _randn((N, K), 2, dev, 0.06).to(torch.bfloat16)
+    h = _randn((M, N), 3, dev).to(torch.bfloat16)
+    ref = rb(a.float() @ w.float().T) + h.float()
+    ops.gemm(a, w, residual=h, out=h)
+    _close(h, ref, atol=4e-3, what="in-place residual")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,C", [(50, 256), (4097, 1024), (1031, 2048), (64, 4096)])
+def test_layernorm(dev, rows, C):
+    from actionmesh_amd import ops
+    x = (_randn((rows, C), 1, dev) * 2.0 + 0.5).to(torch.bfloat16)
+    w = _randn((C,), 2, dev) * 0.2 + 1.0
+    b = _randn((C,), 3, dev) * 0.2
+    out = ops.layernorm(x, w, b, 1e-5)
+    ref = F.layer_norm(x.float(), (C,), w, b, 1e-5)
+    _close(out, ref, ulps=1.5, atol=1e-5, what=f"layernorm {rows}x{C}")
+
+
+# ------------------------------------------------------------------------------------------
+def _headpost_ref(x, heads, nparts, part, w, rope, seq_len, rpf):
+    rows = x.shape[0]
+    xs = x.float().view(rows, heads, nparts, 128)[:, :, part]          # (rows, H, 128)
+    if w is not None:
+        xs = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    if rope is not None:
+        cos, sin = rope
+        fr = torch.arange(rows, device=x.device) // rpf
+        c = cos[fr].repeat_interleave(2, dim=-1)[:, None]
+        s = sin[fr].repeat_interleave(2, dim=-1)[:, None]
+        xr, xi = xs.reshape(rows, heads, 64, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], -1).flatten(2)
+        xs = xs * c + rot * s
+    nseq = rows // seq_len
+    return xs.view(nseq, seq_len, heads, 128).permute(0, 2, 1, 3)      # (nseq, H, S, 128)
+
+
+@pytest.mark.parametrize("nseq,frames_per_seq,L,heads", [(2, 4, 49, 2), (1, 3, 70, 3), (6, 1, 130, 2)])
+def test_head_post_self(dev, nseq, frames_per_seq, L, heads):
+    from actionmesh_amd import ops
+    seq_len = frames_per_seq * L
+    rows = nseq * seq_len
+    x = _randn((rows, heads * 3 * 128), 1, dev).to(torch.bfloat16)
+    wq = _randn((128,), 2, dev) * 0.2 + 1.0
+    wk = _randn((128,), 3, dev) * 0.2 + 1.0
+    nfr = nseq * frames_per_seq
+    ang = _randn((nfr, 64), 4, dev) * 3.0
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q, k, vt = ops.head_post(x, heads, (0, 1, 2), seq_len, L, w_q=wq, w_k=wk, rope=(cos, sin))
+    torch.cuda.synchronize()
+    qr = _headpost_ref(x, heads, 3, 0, wq, (cos, sin), seq_len, L)
+    kr = _headpost_ref(x, heads, 3, 1, wk, (cos, sin), seq_len, L)
+    vr = _headpost_ref(x, heads, 3, 2, None, None, seq_len, L)
+    _close(q[:, :, :seq_len], qr, ulps=1.5, atol=1e-5, what="head_post Q")
+    _close(k[:, :, :seq_len], kr, ulps=1.5, atol=1e-5, what="head_post K")
+    assert bool((q[:, :, seq_len:] == 0).all()) and bool((k[:, :, seq_len:] == 0).all())
+    sk_pad = vt.shape[-1]
+    idx = ops.perm16_index(sk_pad, dev)
+    vpad = torch.zeros((nseq, heads, sk_pad, 128), device=dev)
+    vpad[:, :, :seq_len] = vr
+    assert torch.equal(vt.float(), vpad[:, :, idx].transpose(-1, -2).contiguous()), "V^T layout / perm16"
+
+
+def test_head_post_cross(dev):
+    """cross branch: q only (norm, no rope) and [k|v] pairs from the context (attention_processor.py:111-115)."""
+    from actionmesh_amd import ops
+    heads, L, S, BT = 2, 49, 9, 5
+    xq = _randn((BT * L, heads * 128), 1, dev).to(torch.bfloat16)
+    wq = _randn((128,), 2, dev) * 0.2 + 1.0
+    q, _, _ = ops.head_post(xq, heads, (0,), L, L, w_q=wq)
+    _close(q[:, :, :L], _headpost_ref(xq, heads, 1, 0, wq, None, L, L), ulps=1.5, atol=1e-5, what="cross Q")
+    xkv = _randn((BT * S, heads * 2 * 128), 3, dev).to(torch.bfloat16)
+    wk = _randn((128,), 4, dev) * 0.2 + 1.0
+    _, k, vt = ops.head_post(xkv, heads, (1, 2), S, S, w_k=wk)
+    _close(k[:, :, :S], _headpost_ref(xkv, heads, 2, 0, wk, None, S, S), ulps=1.5, atol=1e-5, what="cross K")
+    vr = _headpost_ref(xkv, heads, 2, 1, None, None, S, S)
+    idx = ops.perm16_index(vt.shape[-1], dev)
+    vpad = torch.zeros((BT, heads, vt.shape[-1], 128), device=dev)
+    vpad[:, :, :S] = vr
+    assert torch.equal(vt.float(), vpad[:, :, idx].transpose(-1, -2).contiguous())
+
+
+# ------------------------------------------------------------------------------------------
+def _layout(q, k, v, nchunks=1):
+    """(nseq,H,S,128) tensors -> padded kernel operands; keys split in `nchunks` equal chunks."""
+    from actionmesh_amd import ops
+    nseq, H, sq, _ = q.shape
+    sk = k.shape[2]
+    assert sk % nchunks == 0
+    skc = sk // nchunks
+    sq_pad, sk_pad = ops.round_up(sq, 256), ops.round_up(skc, 64)
+    dev = q.device
+    Q = torch.zeros((nseq, H, sq_pad, 128), dtype=torch.bfloat16, device=dev)
+    Q[:, :, :sq] = q
+    K = torch.zeros((nchunks, nseq, H, sk_pad, 128), dtype=torch.bfloat16, device=dev)
+    Vt = torch.zeros((nchunks, nseq, H, 128, sk_pad), dtype=torch.bfloat16, device=dev)
+    idx = ops.perm16_index(sk_pad, dev)
+    for c in range(nchunks):
+        K[c, :, :, :skc] = k[:, :, c * skc:(c + 1) * skc]
+        vp = torch.zeros((nseq, H, sk_pad, 128), dtype=torch.bfloat16, device=dev)
+        vp[:, :, :skc] = v[:, :, c * skc:(c + 1) * skc]
+        Vt[c] = vp[:, :, idx].transpose(-1, -2)
+    return Q, K, Vt, skc
+
+
+def _sdpa_ref(q, k, v):
+    s = (q.float() @ k.float().transpose(-1, -2)) * (128 ** -0.5)
+    return torch.softmax(s, dim=-1) @ v.float()
+
+
+@pytest.mark.parametrize("nseq,H,sq,sk,nchunks", [(1, 2, 300, 300, 1), (2, 2, 196, 196, 1), (5, 2, 49, 9, 1),
+                                                  (3, 2, 70, 17, 1), (1, 1, 1000, 64, 1), (2, 2, 196, 196, 2),
+                                                  (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1)])
+@pytest.mark.parametrize("defer", [0, 8])
+def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
+    from actionmesh_amd import ops
+    q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)
+    k = _randn((nseq, H, sk, 128), 2, dev).to(torch.bfloat16)
+    v = _randn((nseq, H, sk, 128), 3, dev).to(torch.bfloat16)
+    Q, K, Vt, skc = _layout(q, k, v, nchunks)
+    out = ops.attention(Q, K, Vt, sq, skc, nchunks=nchunks, defer_log2=defer)
+    torch.cuda.synchronize()
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+    err = (out.float() - ref).abs().max().item()
+    assert err < 2e-2, f"attention max abs err {err:.4e} (ref max {ref.abs().max().item():.3f})"
+
+
+def test_attention_forced_rescale_branch(dev):
+    """A key that dominates late in the stream forces the online-softmax rescale branch with the
+    deferred-rescale threshold active (cdna guide section 5.4 rule 26); threshold 0 and 8 must agree."""
+    from actionmesh_amd import ops
+    nseq, H, sq, sk = 1, 1, 256, 640
+    q = _randn((nseq, H, sq, 128), 1, dev)
+    k = _randn((nseq, H, sk, 128), 2, dev) * 0.3
+    v = _randn((nseq, H, sk, 128), 3, dev)
+    for (row, key, gain) in ((7, 333, 6.0), (100, 500, 12.0), (255, 639, 20.0), (31, 70, 9.0)):
+        k[0, 0, key] = q[0, 0, row] * gain / q[0, 0, row].norm() * 11.3 / 3.0
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    Q, K, Vt, skc = _layout(q, k, v, 1)
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(sq, 128)
+    outs = []
+    for defer in (0, 8):
+        o = ops.attention(Q, K, Vt, sq, skc, defer_log2=defer).float()
+        assert (o - ref).abs().max().item() < 3e-2, f"defer={defer}"
+        outs.append(o)
+    assert (outs[0] - outs[1]).abs().max().item() < 3e-2
+
+
+def test_attention_properties_full_size(dev):
+    """BASELINE headline sequence (16 frames x 4097 tokens), one head: size-independent properties.
+    (a) V == 1 -> output == 1 (softmax rows sum to 1), (b) permuting key chunks leaves the output
+    unchanged, (c) sampled query rows equal the fp32 reference on the full 65 552 keys."""
+    from actionmesh_amd import ops
+    T, L = 16, 4097
+    S = T * L
+    q = _randn((1, 1, S, 128), 1, dev).to(torch.bfloat16)
+    k = _randn((1, 1, S, 128), 2, dev).to(torch.bfloat16)
+    v = _randn((1, 1, S, 128), 3, dev).to(torch.bfloat16)
+    Q, K, Vt, skc = _layout(q, k, v, 4)
+    out = ops.attention(Q, K, Vt, S, skc, nchunks=4).float()
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 4096, 4097, 40000, S - 17, S - 1], device=dev)
+    ref = _sdpa_ref(q[:, :, rows], k, v)[0, 0]
+    assert (out[rows] - ref).abs().max().item() < 5e-3
+    Kp = K[[2, 0, 3, 1]].contiguous(); Vp = Vt[[2, 0, 3, 1]].contiguous()
+    outp = ops.attention(Q, Kp, Vp, S, skc, nchunks=4).float()
+    assert (outp - out).abs().max().item() < 5e-3
+    ones = torch.ones_like(Vt)
+    o1 = ops.attention(Q, K, ones, S, skc, nchunks=4).float()
+    assert (o1 - 1.0).abs().max().item() < 8e-3
+
+
+# ------------------------------------------------------------------------------------------
+def test_timestep_sinusoid(dev):
+    from actionmesh_amd import ops
+    t = torch.tensor([1000.0, 0.0, 8.9285717, 523.25, 964.40027], device=dev)
+    out = ops.timestep_sinusoid(t, 256).float()
+    half = 128
+    f = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=dev) / half)
+    ref = torch.cat([torch.sin(t[:, None] * f), torch.cos(t[:, None] * f)], -1)
+    assert (out - ref).abs().max().item() < 6e-3    # bf16 output + fp32 range reduction at |arg| <= 1000
+
+
+def test_flow_step(dev):
+    from actionmesh_amd import ops
+    T, N, D = 4, 48, 64
+    v = _randn((2, T, N, D), 1, dev).to(torch.bfloat16)
+    lat = _randn((T, N, D), 2, dev)
+    lat0 = lat.clone()
+    ops.flow_step(v, lat, [7.5], 0.0356, True, [False, True, True, False])
+    v0, v1 = v[0].float(), v[1].float()
+    agg = rb(v0 + rb(7.5 * rb(v1 - v0)))
+    ref = lat0 + rb(0.0356 * agg)
+    assert torch.equal(lat[0], lat0[0]) and torch.equal(lat[3], lat0[3])
+    assert torch.allclose(lat[1:3], ref[1:3], rtol=0, atol=1e-6)
+    # 3-branch guidance + subtractive flow, all frames
+    v3 = _randn((3, T, N, D), 3, dev).to(torch.bfloat16)
+    lat = lat0.clone()
+    ops.flow_step(v3, lat, [2.0, 3.0], 0.1, False, None)
+    a, b, c = (v3[i].float() for i in range(3))
+    agg = rb(rb(a + rb(2.0 * rb(b - a))) + rb(3.0 * rb(c - b)))
+    assert torch.allclose(lat, lat0 - rb(0.1 * agg), rtol=0, atol=1e-6)
+
+
+def test_f32_to_bf16(dev):
+    from actionmesh_amd import ops
+    x = _randn((1000003,), 1, dev) * 100
+    assert torch.equal(ops.f32_to_bf16(x), x.to(torch.bfloat16))

@@ -69,8 +69,9 @@ def exchange_kv(kv: Tuple[torch.Tensor, torch.Tensor], plan: FrameShardPlan,
     """All-gather the K and V^T shards in place.  `kv` tensors are (world, chunk)
     views; rank r has written row r."""
     for buf in kv:
-        assert buf.shape[0] == plan.world
-        dist.all_gather_into_tensor(buf, buf[plan.rank], group=group)
+        assert buf.shape[0] == plan.world and buf.is_contiguous()
+        # flat views: accepted by both RCCL and gloo; input aliases its slot of the output
+        dist.all_gather_into_tensor(buf.view(-1), buf[plan.rank].view(-1), group=group)
 
 
 def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],

@@ -115,8 +115,22 @@ def cpu_baseline(hp, sd, step_flops_full, S):
                          num_attention_heads=hp["num_attention_heads"], width=hp["width"],
                          mlp_ratio=hp["mlp_ratio"], cross_attention_dim=hp["cross_attention_dim"],
                          inflated_layers=tuple(hp["inflated_layers"]))
-    Ts, Ns = 8, 512
-    cores = os.cpu_count() or 1
+    Ts, Ns = 8, 256
+    # pick the thread count that gives the best fp32 GEMM rate on this host (big multi-socket
+    # boxes get slower when every hardware thread is used)
+    best, cores = 0.0, 1
+    a = torch.randn(2048, 1024); b = torch.randn(1024, 4096)
+    for n in (8, 16, 32, 64, 128, os.cpu_count() or 1):
+        if n > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(n)
+        a @ b
+        t0 = time.perf_counter()
+        for _ in range(3):
+            a @ b
+        r = 3 * 2 * 2048 * 1024 * 4096 / (time.perf_counter() - t0)
+        if r > best:
+            best, cores = r, n
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, Ts, Ns, hp["in_channels"], generator=g)

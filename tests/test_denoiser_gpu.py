@@ -122,7 +122,11 @@ def test_reference_style_loop_over_hipdenoiser(dev, golden_dir):
         dt = torch.tensor([float(ts[i])], device=dev).expand(2)
         v, cache = model.forward(x_in, c_in, f_in, dt, m_in, cache)
         v = cfgd.aggregate_cfg(v)
-        flow = lat + ds[i].to(dev) * v
+        # NOTE: the reference writes `distances[i] * output_pred` with a 0-dim fp32 DEVICE tensor,
+        # which torch type promotion rounds to bf16 before the multiply (a cuda-autocast artefact
+        # absent from its fp32 CPU path).  The HIP path keeps dt in fp32 (closer to the fp32
+        # reference; DESIGN.md "dtype flow"), so the glue here does the same.
+        flow = lat + (float(ds[i]) * v.float()).to(torch.bfloat16)
         lat[unobs] = flow[unobs]
     a = sched.denoise(model, cfgd, init_latent=t["init_latent"].clone().to(dev), context=ctx, device=dev,
                       mask=mask, framestep=fs)

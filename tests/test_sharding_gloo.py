@@ -1,0 +1,171 @@
+"""N>1 path on CPU: world_size-2 gloo run of the frame-sharded forward driver
+(actionmesh_amd/sharding.py) with an oracle-backed stand-in engine that follows the same phase
+protocol as the HIP engine (begin / layer_pre -> K/V all-gather -> layer_post / end).  Checks the
+shard plan, the chunked K/V gather layout and the exchange against the unsharded oracle."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from actionmesh_amd.sharding import FrameShardPlan, gather_frames, sharded_forward
+from oracle import denoiser_oracle as O
+
+KW = dict(in_channels=64, num_layers=5, num_attention_heads=2, width=256, mlp_ratio=4.0,
+          cross_attention_dim=64, inflated_layers=(0, 1, 3, 4))
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine (tests only): same phases, K/V shards in (world, chunk) buffers."""
+
+    def __init__(self, sd, cfg, plan, ctx_local, cos_local, sin_local, B, N):
+        self.sd, self.cfg, self.plan = sd, cfg, plan
+        self.num_layers = cfg.num_layers
+        self.P = O.Precision("fp32")
+        self.ctx = ctx_local.reshape(-1, ctx_local.shape[2], ctx_local.shape[3])
+        self.cos, self.sin = cos_local, sin_local
+        Tl, L, C = plan.frames_local, N + 1, cfg.width
+        self.chunk = B * Tl * L * C
+        self.k = torch.zeros(plan.world, self.chunk)
+        self.v = torch.zeros(plan.world, self.chunk)
+
+    def is_inflated(self, i):
+        return i in self.cfg.inflated_layers
+
+    def kv_buffers(self):
+        return self.k, self.v
+
+    def begin(self, x, t_bt):
+        sd, cfg, P = self.sd, self.cfg, self.P
+        B, T, N, D = x.shape
+        self.B, self.T, self.N, self.L = B, T, N, N + 1
+        h = P.linear(x.reshape(B * T, N, D), sd["proj_in.weight"], sd["proj_in.bias"])
+        e = O.timestep_sinusoid(torch.tensor(t_bt), cfg.width)
+        e = P.linear(e, sd["time_proj.linear_1.weight"], sd["time_proj.linear_1.bias"])
+        e = P.linear(F.gelu(e), sd["time_proj.linear_2.weight"], sd["time_proj.linear_2.bias"])
+        self.h = torch.cat([e[:, None], h], 1)
+        self.skips = []
+
+    def layer_pre(self, i):
+        sd, cfg, P = self.sd, self.cfg, self.P
+        p = f"blocks.{i}."
+        H, hd = cfg.num_attention_heads, cfg.head_dim
+        if cfg.has_skip(i):
+            cat = torch.cat([self.skips.pop(), self.h], -1)
+            self.h = O.fp32_layer_norm(P.linear(cat, sd[p + "linear_skip.weight"], sd[p + "linear_skip.bias"]),
+                                       sd[p + "norm_skip.weight"], sd[p + "norm_skip.bias"])
+        z = O.fp32_layer_norm(self.h, sd[p + "norm_s_attn.weight"], sd[p + "norm_s_attn.bias"])
+        BT, L, C = z.shape
+        qkv = torch.cat([P.linear(z, sd[p + f"s_attn.{n}.weight"], None) for n in ("to_q", "to_k", "to_v")], -1)
+        q, k, v = torch.split(qkv.view(BT, L, H, 3 * hd), hd, dim=-1)           # (BT, L, H, hd)
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))                         # (BT, H, L, hd)
+        cos = self.cos[:, None, :].expand(BT, L, hd); sin = self.sin[:, None, :].expand(BT, L, hd)
+        q = O.apply_rope(O.rms_norm(q, sd[p + "s_attn.norm_q.weight"]), cos, sin)
+        k = O.apply_rope(O.rms_norm(k, sd[p + "s_attn.norm_k.weight"]), cos, sin)
+        self.q = q
+        r = self.plan.rank if self.is_inflated(i) else 0
+        self.k[r] = k.reshape(-1)
+        self.v[r] = v.reshape(-1)
+
+    def layer_post(self, i):
+        sd, cfg, P = self.sd, self.cfg, self.P
+        p = f"blocks.{i}."
+        H, hd, B, T, L = cfg.num_attention_heads, cfg.head_dim, self.B, self.T, self.L
+        C = cfg.width
+        shp = (B * T, H, L, hd)
+        if self.is_inflated(i):
+            # every chunk is (B, T_local, H, L, hd); keys of all chunks are simply concatenated
+            ks = [self.k[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.world)]
+            vs = [self.v[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.world)]
+            q = self.q.view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd)
+            o = F.scaled_dot_product_attention(q, torch.cat(ks, 2), torch.cat(vs, 2))
+            o = o.view(B, H, T, L, hd).permute(0, 2, 3, 1, 4).reshape(B * T, L, C)
+        else:
+            o = F.scaled_dot_product_attention(self.q, self.k[0].view(shp), self.v[0].view(shp))
+            o = o.transpose(1, 2).reshape(B * T, L, C)
+        h = self.h + P.linear(o, sd[p + "s_attn.to_out.0.weight"], sd[p + "s_attn.to_out.0.bias"])
+        z = O.fp32_layer_norm(h, sd[p + "norm_x_attn.weight"], sd[p + "norm_x_attn.bias"])
+        h = h + O.cross_attention(z, self.ctx, sd, p + "x_attn.", H, P)
+        z = O.fp32_layer_norm(h, sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"])
+        u = F.gelu(P.linear(z, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"]))
+        self.h = h + P.linear(u, sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"])
+        if i < cfg.num_layers // 2:
+            self.skips.append(self.h)
+
+    def end(self):
+        sd = self.sd
+        h = O.fp32_layer_norm(self.h, sd["norm_out.weight"], sd["norm_out.bias"])[:, -self.N:]
+        return self.P.linear(h, sd["proj_out.weight"], sd["proj_out.bias"]).reshape(self.B, self.T, self.N, -1)
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(5)
+    B, T, N, S = 2, 4, 20, 7
+    x = torch.randn(B, T, N, 64, generator=g)
+    ctx = torch.randn(B, T, S, 64, generator=g); ctx[0] = 0
+    fs = torch.tensor([[2.0, 0.0, 1.0, 3.0]]).repeat(B, 1)
+    mask = torch.zeros(B, T); mask[:, 0] = 1
+    t = torch.tensor([640.0, 640.0])
+    return x, ctx, fs, mask, t
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from actionmesh_amd.denoiser import masked_time, rope_tables_host
+        torch.set_num_threads(2)
+        cfg = O.OracleConfig(**KW)
+        sd = O.synthetic_state_dict(cfg, seed=0)
+        x, ctx, fs, mask, t = _inputs()
+        B, T, N, _ = x.shape
+        plan = FrameShardPlan(T, world, rank)
+        cos, sin = rope_tables_host(fs, 128)                         # from the FULL window's framesteps
+        cos = cos.repeat_interleave(2, -1).view(B, T, -1)[:, plan.frame_slice].reshape(-1, 128)
+        sin = sin.repeat_interleave(2, -1).view(B, T, -1)[:, plan.frame_slice].reshape(-1, 128)
+        eng = OracleEngine(sd, cfg, plan, plan.slice_frames(ctx), cos, sin, B, N)
+        t_bt = masked_time(t.tolist(), mask, B, T)
+        tl = plan.frames_local
+        t_local = [t_bt[b * T + rank * tl + j] for b in range(B) for j in range(tl)]
+        v_local = sharded_forward(eng, plan, None, plan.slice_frames(x), t_local)
+        v = gather_frames(v_local, plan, None)
+        if rank == 0:
+            q.put(v)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_sharded_forward_equals_unsharded_oracle():
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29400 + os.getpid() % 500
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    v = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg = O.OracleConfig(**KW)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x, ctx, fs, mask, t = _inputs()
+    ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
+    assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5), float((v - ref).abs().max())
+
+
+def test_world1_driver_is_identity_plan():
+    cfg = O.OracleConfig(**KW)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    from actionmesh_amd.denoiser import masked_time, rope_tables_host
+    x, ctx, fs, mask, t = _inputs()
+    B, T, N, _ = x.shape
+    plan = FrameShardPlan(T, 1, 0)
+    cos, sin = rope_tables_host(fs, 128)
+    eng = OracleEngine(sd, cfg, plan, ctx, cos.repeat_interleave(2, -1), sin.repeat_interleave(2, -1), B, N)
+    v = sharded_forward(eng, plan, None, x, masked_time(t.tolist(), mask, B, T))
+    ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
+    assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Per-kernel timing at the headline (or nominal) layer shapes, HIP events on the launch stream.
+    python tools/kernel_bench.py [--shape headline|nominal] [--only attn,gemm,ln,post] [--reps 3]
+Prints one line per kernel: ms, TFLOP/s (MFMA kernels) or GB/s (HBM-bound kernels)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from actionmesh_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="headline")
+    ap.add_argument("--only", default="attn,xattn,gemm,ln,post")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--defer", type=int, default=8)
+    a = ap.parse_args()
+    T, N, C, H, S = (16, 4096, 1024, 8, 257) if a.shape == "headline" else (16, 2048, 2048, 16, 257)
+    B, L = 2, N + 1
+    R = B * T * L
+    dev = torch.device("cuda:0")
+    only = set(a.only.split(","))
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(s, device=dev, generator=g).to(torch.bfloat16)
+    if "attn" in only:
+        Sq = T * L
+        Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
+        Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
+        ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=a.defer), a.reps)
+        fl = 4.0 * Sq * Sq * C * B
+        print(f"self-attn  B={B} H={H} S={Sq}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        del Q, K, Vt, out
+    if "xattn" in only:
+        BT = B * T
+        Q = rnd(BT, H, ops.round_up(L, 256), 128); K = rnd(BT, H, ops.round_up(S, 64), 128)
+        Vt = rnd(BT, H, 128, ops.round_up(S, 64)); out = torch.empty((BT * L, C), dtype=torch.bfloat16, device=dev)
+        ms = timeit(lambda: ops.attention(Q, K, Vt, L, S, out=out, defer_log2=a.defer), a.reps)
+        fl = 4.0 * BT * L * S * C
+        print(f"cross-attn BT={BT} H={H} L={L} S={S}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        del Q, K, Vt, out
+    if "gemm" in only:
+        F_ = 4 * C
+        for name, Nn, Kk, kw in (("qkv", 3 * C, C, {}), ("attn-out+res", C, C, {"res": True, "bias": True}),
+                                 ("ff1+gelu", F_, C, {"bias": True, "gelu": True}),
+                                 ("ff2+res", C, F_, {"bias": True, "res": True}),
+                                 ("skip(2C)", C, 2 * C, {"bias": True})):
+            A = rnd(R, Kk); W = rnd(Nn, Kk); out = torch.empty((R, Nn), dtype=torch.bfloat16, device=dev)
+            bias = torch.randn(Nn, device=dev) if kw.get("bias") else None
+            res = rnd(R, Nn) if kw.get("res") else None
+            ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out), a.reps)
+            print(f"gemm {name:13s} M={R} N={Nn} K={Kk}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            del A, W, out, res
+    if "ln" in only:
+        x = rnd(R, C); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)
+        ms = timeit(lambda: ops.layernorm(x, w, b, out=y), a.reps)
+        print(f"layernorm  rows={R} C={C}: {ms:8.3f} ms  {2.0 * R * C * 2 / ms / 1e6:8.1f} GB/s")
+    if "post" in only:
+        x = rnd(R, 3 * C); wq = torch.ones(128, device=dev)
+        cos = torch.randn(B * T, 64, device=dev); sin = torch.randn(B * T, 64, device=dev)
+        q, k, vt = ops.head_post(x, H, (0, 1, 2), T * L, L, w_q=wq, w_k=wq, rope=(cos, sin))
+        ms = timeit(lambda: ops.head_post(x, H, (0, 1, 2), T * L, L, w_q=wq, w_k=wq, rope=(cos, sin),
+                                          out_q=q, out_k=k, out_vt=vt), a.reps)
+        print(f"head_post  rows={R} 3C={3 * C}: {ms:8.3f} ms  {2.0 * R * 3 * C * 2 / ms / 1e6:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -5,8 +5,7 @@
 //
 // Work decomposition: one workgroup = 8 waves = 256 query rows of one
 // (sequence, head); each wave owns 32 query rows.  Keys/values stream through
-// LDS in tiles of 64 keys, double-buffered, staged global -> VGPR -> LDS with
-// the loads of tile t+1 issued before the math of tile t (one barrier/tile).
+// LDS in tiles of 64 keys, double-buffered, staged global -> VGPR -> LDS.
 //
 // MFMA formulation (v_mfma_f32_32x32x16_bf16, "swapped" so that the softmax
 // row is lane-local and P never leaves registers):
@@ -19,6 +18,18 @@
 // (j&3)+8(j>>2)+4hi of its 16-key group, so V^T is stored (by am_head_post)
 // with keys permuted inside each group of 16 (perm16: bit2<->bit3) and the
 // matching A-operand is one contiguous 16-byte LDS read.
+//
+// Schedule (STAGGER = true): a CU holds one workgroup = two waves per SIMD
+// (wave i and wave i+4 share SIMD i).  Waves 4-7 run exactly one phase behind
+// waves 0-3 (they take one extra s_barrier before the loop, waves 0-3 one
+// after it), and every tile is two phases separated by barriers:
+//   phase 1: S^T = K Q^T (16 MFMA)          | also: LDS-write K(t+1), issue V(t+1) loads
+//   phase 2: softmax (VALU) then P.V (16 MFMA) | also: issue K(t+2) loads, LDS-write V(t+1)
+// so on every SIMD one wave's QK^T MFMAs run beside its partner's softmax
+// VALU work and are followed by the partner's P.V MFMAs: the matrix pipe is
+// never idle during a softmax.  Each half-workgroup stages its own half of
+// every K / V^T tile; the hazard analysis (which global phase may write which
+// LDS buffer) is in DESIGN.md section "attention".
 //
 // Multi-GPU: K/V arrive as `nchunks` frame shards ([chunk][seq][head]...);
 // softmax is permutation-invariant over keys, so chunks are simply
@@ -36,9 +47,7 @@ constexpr int K_TILE = KVBLK * K_LD;
 constexpr int V_TILE = HD * V_LD;
 constexpr int SMEM_BYTES = 2 * (K_TILE + V_TILE) * (int)sizeof(bf16_t);   // 71680
 
-__device__ inline uint32_t pack2_rn(float a, float b) { return pack_bf2(a, b); }
-
-template <int DEFER>
+template <int DEFER, bool STAGGER>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int tiles_per_chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [2][64][K_LD]
@@ -50,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   const int bh = blockIdx.y;                          // sequence * heads + head
   const int head = bh % p.heads, seq = bh / p.heads;
   const int q0 = blockIdx.x * QBLK + wave * 32;
+  const bool late = STAGGER && (__builtin_amdgcn_readfirstlane(tid) >= 256);   // waves 4-7: one phase behind
 
   // ---- Q fragments (B operand): Q[q0 + l31][ks*16 + hi*8 .. +8] -------------
   bf16x8_t qf[8];
@@ -59,13 +69,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
   }
 
-  // ---- K / V^T tile staging ---------------------------------------------------
-  // K tile: 64 keys x 256 B -> 1024 x 16 B, two per thread.
-  // V^T tile: 128 d-rows x 128 B -> 1024 x 16 B, two per thread.
+  // ---- K / V^T tile staging: 1024 x 16 B each, two per thread.  With STAGGER each
+  // half-workgroup (256 threads) owns one half of every tile: c in [half*512, half*512+512).
   int k_src_off[2], v_src_row[2], v_src_col[2], k_lds[2], v_lds[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int c = tid + 512 * i;
+    const int c = STAGGER ? ((tid >> 8) * 512 + (tid & 255) + 256 * i) : (tid + 512 * i);
     const int krow = c >> 4, kcol = (c & 15) * 8;
     k_src_off[i] = krow * HD + kcol;
     k_lds[i] = krow * K_LD + kcol;
@@ -78,23 +87,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   const int total_tiles = p.nchunks * tiles_per_chunk;
 
   u32x4_t kreg[2], vreg[2];
-  auto load_tile = [&](int t) {
+  auto tile_base = [&](int t, const bf16_t*& kb, const bf16_t*& vb) {
     const int chunk = t / tiles_per_chunk;
     const int tt = t - chunk * tiles_per_chunk;
-    const bf16_t* kb = p.K + (int64_t)chunk * p.chunk_stride + (int64_t)bh * k_seq_stride + (int64_t)tt * KVBLK * HD;
-    const bf16_t* vb = p.Vt + (int64_t)chunk * p.chunk_stride + (int64_t)bh * k_seq_stride + (int64_t)tt * KVBLK;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + k_src_off[i]);
-      vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)v_src_row[i] * p.sk_pad + v_src_col[i]);
-    }
+    const int64_t off = (int64_t)chunk * p.chunk_stride + (int64_t)bh * k_seq_stride;
+    kb = p.K + off + (int64_t)tt * KVBLK * HD;
+    vb = p.Vt + off + (int64_t)tt * KVBLK;
   };
-  auto store_tile = [&](int buf) {
+  auto load_k = [&](int t) {
+    const bf16_t *kb, *vb;
+    tile_base(t, kb, vb);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<u32x4_t*>(&Ks[buf * K_TILE + k_lds[i]]) = kreg[i];
-      *reinterpret_cast<u32x4_t*>(&Vs[buf * V_TILE + v_lds[i]]) = vreg[i];
-    }
+    for (int i = 0; i < 2; ++i) kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + k_src_off[i]);
+  };
+  auto load_v = [&](int t) {
+    const bf16_t *kb, *vb;
+    tile_base(t, kb, vb);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)v_src_row[i] * p.sk_pad + v_src_col[i]);
+  };
+  auto store_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Ks[buf * K_TILE + k_lds[i]]) = kreg[i];
+  };
+  auto store_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Vs[buf * V_TILE + v_lds[i]]) = vreg[i];
   };
 
   f32x16_t o[4];
@@ -106,19 +125,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   float l_run = 0.f;         // this half-lane's partial row sum
   const float c = p.scale * 1.4426950408889634f;
 
-  load_tile(0);
-  store_tile(0);
-
   const int k_frag = l31 * K_LD + hi * 8;
   const int v_frag = l31 * V_LD + hi * 8;
+  f32x16_t s[2];
 
-  for (int t = 0; t < total_tiles; ++t) {
-    __syncthreads();
+  // ---- phase 1: S^T = K Q^T -----------------------------------------------------
+  auto qk_phase = [&](int t) {
     const int buf = t & 1;
-    if (t + 1 < total_tiles) load_tile(t + 1);
-
-    // ---- S^T = K Q^T -----------------------------------------------------------
-    f32x16_t s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -130,9 +143,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
       }
     }
+  };
 
-    // ---- mask the padded keys of a chunk's last tile -----------------------------
-    {
+  // ---- phase 2: online softmax (row = this lane's query), then O^T += V^T P^T -------
+  auto softmax_pv_phase = [&](int t) {
+    const int buf = t & 1;
+    {   // mask the padded keys of a chunk's last tile
       const int chunk = t / tiles_per_chunk;
       const int tt = t - chunk * tiles_per_chunk;
       const int valid = p.sk - tt * KVBLK;      // wave-uniform
@@ -146,8 +162,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
           }
       }
     }
-
-    // ---- online softmax (row = this lane's query) ----------------------------------
     float mx = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -177,19 +191,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
         rs += pv;
       }
     l_run += rs;
-
-    // ---- P^T fragments (B operand), straight from the S registers ------------------
+    // P^T fragments (B operand), straight from the S registers
     bf16x8_t pf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       u32x4_t w;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        w[e] = pack2_rn(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+        w[e] = pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
       pf[kk] = __builtin_bit_cast(bf16x8_t, w);
     }
-
-    // ---- O^T += V^T P^T ---------------------------------------------------------------
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const bf16_t* vp = Vs + buf * V_TILE + v_frag + kk * 16;
@@ -199,8 +210,39 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kk], o[d], 0, 0, 0);
       }
     }
+  };
 
-    if (t + 1 < total_tiles) store_tile(buf ^ 1);
+  if (STAGGER) {
+    // prologue: tile 0 complete in buffer 0 (each half-workgroup brings its half), K(1) in flight
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    if (total_tiles > 1) load_k(1);
+    if (late) __syncthreads();                  // waves 4-7 start one phase late
+    for (int t = 0; t < total_tiles; ++t) {
+      __syncthreads();                          // ---- phase 1 of tile t
+      if (t + 1 < total_tiles) load_v(t + 1);
+      qk_phase(t);
+      if (t + 1 < total_tiles) store_k((t + 1) & 1);
+      __syncthreads();                          // ---- phase 2 of tile t
+      if (t + 2 < total_tiles) load_k(t + 2);
+      softmax_pv_phase(t);
+      if (t + 1 < total_tiles) store_v((t + 1) & 1);
+    }
+    if (!late) __syncthreads();                 // balance the barrier count
+  } else {
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    for (int t = 0; t < total_tiles; ++t) {
+      __syncthreads();
+      if (t + 1 < total_tiles) { load_k(t + 1); load_v(t + 1); }
+      qk_phase(t);
+      softmax_pv_phase(t);
+      if (t + 1 < total_tiles) { store_k((t + 1) & 1); store_v((t + 1) & 1); }
+    }
   }
 
   // ---- normalise and store O[q][head*128 + d] ---------------------------------------
@@ -214,30 +256,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t w;
-        w[0] = pack2_rn(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
-        w[1] = pack2_rn(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
         *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
       }
   }
 }
 
-template <int DEFER>
+template <int DEFER, bool STAGGER>
 int launch(const am_attn_args* a, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, STAGGER>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     attr_set = true;
   }
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
-  hipLaunchKernelGGL(attn_fwd_kernel<DEFER>, grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a, tiles_per_chunk);
+  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, STAGGER>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
+                     tiles_per_chunk);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }
 
 }  // namespace
 
+// defer_log2: 0 or 8 = deferred-rescale threshold; add 100 to select the un-staggered
+// (lockstep) schedule, kept for A/B measurements (tools/kernel_bench.py --variant).
 extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_attention_bf16: null args");
   AM_CHECK(a->Q && a->K && a->Vt && a->O, "am_attention_bf16: null operand");
@@ -255,8 +300,10 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
   switch (a->defer_log2) {
-    case 0: return launch<0>(a, stream);
-    case 8: return launch<8>(a, stream);
+    case 0: return launch<0, true>(a, stream);
+    case 8: return launch<8, true>(a, stream);
+    case 100: return launch<0, false>(a, stream);
+    case 108: return launch<8, false>(a, stream);
     default: AM_FAIL(AM_ERR_INVALID, "am_attention_bf16: defer_log2 must be 0 or 8 (got %d)", a->defer_log2);
   }
 }

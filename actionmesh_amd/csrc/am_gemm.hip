@@ -191,6 +191,187 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
   }
 }
 
+
+// ===========================================================================
+// v2: 256x256x64 tile, 8 waves (2 x 4, each 128 x 64), operands DMA'd straight
+// into LDS (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
+// The LDS image of a tile is lane-linear per wave-instruction (DMA constraint),
+// so the bank-conflict swizzle is applied to the per-lane SOURCE address and
+// mirrored on the ds_read side: 16-byte unit c of tile row r lives at unit
+// position c ^ ((r >> 1) & 7) of its 128-byte row, which puts the 16 lanes of
+// every ds_read_b128 group on 16 distinct 16-byte slots of the 256-byte bank row.
+// Two LDS buffers (128 KiB): the DMA of K-tile kt+1 runs under the MFMAs of kt.
+// Epilogue: bias/GELU in registers, bf16 tile staged through LDS (XOR-swizzled
+// 8-byte units), then row-contiguous 512-byte stores with the residual add.
+// ===========================================================================
+constexpr int B2 = 256;                        // BM = BN
+constexpr int T2_UNITS = B2 * (BK / 8);        // 16-byte units per operand tile (2048)
+constexpr int T2_BYTES = T2_UNITS * 16;        // 32 KiB
+constexpr int SMEM2_BYTES = 4 * T2_BYTES;      // A,B x 2 buffers = 128 KiB (epilogue reuses it)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  int lid;
+  {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = lid / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    const int in_g = lid - g * group_sz;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = tm * B2, n0 = tn * B2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- DMA source pointers: unit U = j*512 + wave*64 + lane of each tile -----------
+  const bf16_t* a1p[4];
+  const bf16_t* a2p[4];
+  const bf16_t* wp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int U = j * 512 + wave * 64 + lane;
+    const int r = U >> 3, c = (U & 7) ^ ((r >> 1) & 7);
+    const int ar = min(m0 + r, p.M - 1);
+    const int64_t pr = map_row(ar, p.a_G, p.a_gs, p.a_off);
+    a1p[j] = p.A1 + pr * p.lda1 + c * 8;
+    a2p[j] = p.A2 ? p.A2 + pr * p.lda2 + c * 8 - p.K1 : nullptr;
+    const int wr = min(n0 + r, p.N - 1);
+    wp[j] = p.W + (int64_t)wr * p.ldw + c * 8;
+  }
+  auto dma_tile = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    const bool first = k0 < p.K1;
+    unsigned char* abase = smem + buf * 2 * T2_BYTES;
+    unsigned char* bbase = abase + T2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* src = first ? a1p[j] + k0 : a2p[j] + k0;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(abase + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wp[j] + k0), (lds_ptr_t)(bbase + (j * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment byte offsets inside a tile: row R, k-unit c -> (R*8 + (c ^ ((R>>1)&7))) * 16
+  int a_row_off[4], a_sw[4], b_row_off[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = wm * 128 + i * 32 + l31;
+    a_row_off[i] = R * 128;
+    a_sw[i] = (R >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int R = wn * 64 + j * 32 + l31;
+    b_row_off[j] = R * 128;
+    b_sw[j] = (R >> 1) & 7;
+  }
+
+  const int nk = p.K / BK;
+  dma_tile(0, 0);
+  __syncthreads();                   // drains the DMA (vmcnt(0)) and publishes it
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) dma_tile(kt + 1, buf ^ 1);
+    const unsigned char* At = smem + buf * 2 * T2_BYTES;
+    const unsigned char* Bt = At + T2_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int c = ks * 2 + hi;
+      bf16x8_t af[4], bfr[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bt + b_row_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8_t*>(At + a_row_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                 // next tile landed; everyone is done with `buf`
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------
+  // stage[m][n] bf16, row = 512 B = 64 units of 8 B; unit u of row m sits at u ^ (m & 15)
+  unsigned char* stage = smem;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = wn * 64 + j * 32 + 8 * g + 4 * hi;          // 4 consecutive columns
+      f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + nl, p.N - 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ml = wm * 128 + i * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(acc[i][j][4 * g + e] + bv[e]);
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+        }
+        u32x2_t w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        const int u = (nl >> 2) ^ (ml & 15);
+        *reinterpret_cast<u32x2_t*>(stage + ml * 512 + u * 8) = w;
+      }
+    }
+  __syncthreads();
+  {
+    const int k16 = tid & 31;                 // 16-byte chunk (8 columns) of the row
+    const int gn = n0 + k16 * 8;
+    if (gn < p.N) {
+#pragma unroll 4
+      for (int pass = 0; pass < 16; ++pass) {
+        const int ml = pass * 16 + (tid >> 5);
+        const int gmr = m0 + ml;
+        if (gmr < p.M) {
+          const int jj = k16 ^ ((ml & 15) >> 1);
+          u32x4_t sv = *reinterpret_cast<const u32x4_t*>(stage + ml * 512 + jj * 16);
+          if (ml & 1) sv = u32x4_t{sv[2], sv[3], sv[0], sv[1]};
+          const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
+          if (p.residual) {
+            const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(p.residual + pr * p.ldc + gn);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
+          }
+          *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = sv;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
@@ -205,16 +386,29 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
            "am_gemm_bf16: leading dimensions must be multiples of 8 elements (16 B)");
   AM_CHECK(((uintptr_t)a->A1 | (uintptr_t)a->W | (uintptr_t)a->C | (uintptr_t)a->A2 | (uintptr_t)a->residual) % 16 == 0,
            "am_gemm_bf16: operands must be 16-byte aligned");
-  AM_CHECK(a->act == 0 || a->act == 1, "am_gemm_bf16: unknown activation %d", a->act);
   static bool attr_set = false;
   if (!attr_set) {
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
     attr_set = true;
   }
-  const int tiles_m = ceil_div(a->M, BM), tiles_n = ceil_div(a->N, BN);
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), SMEM_BYTES,
-                     (hipStream_t)stream, *a, tiles_m, tiles_n);
+  // act bit 8 (0x100) forces the 128x128 register-staged kernel (A/B measurements / tests)
+  am_gemm_args args = *a;
+  const bool force_small = (args.act & 0x100) != 0;
+  args.act &= 0xff;
+  AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
+  const bool big = !force_small && args.N >= 256 && args.M >= 1024;
+  if (big) {
+    const int tiles_m = ceil_div(args.M, B2), tiles_n = ceil_div(args.N, B2);
+    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
+                       (hipStream_t)stream, args, tiles_m, tiles_n);
+  } else {
+    const int tiles_m = ceil_div(args.M, BM), tiles_n = ceil_div(args.N, BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), SMEM_BYTES,
+                       (hipStream_t)stream, args, tiles_m, tiles_n);
+  }
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

@@ -129,25 +129,44 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   const int v_frag = l31 * V_LD + hi * 8;
   f32x16_t s[2];
 
-  // ---- phase 1: S^T = K Q^T -----------------------------------------------------
+  // ---- phase 1: S^T = K Q^T.  The 16 K fragments are read 8 deep ahead of the MFMAs that
+  // consume them (LDS latency ~100+ cycles vs 32 cycles per MFMA): 8 reads up front, then every
+  // MFMA of the first key block re-fills its fragment slot with the second block's fragment.
   auto qk_phase = [&](int t) {
     const int buf = t & 1;
+    const bf16_t* kp0 = Ks + buf * K_TILE + k_frag;
+    const bf16_t* kp1 = kp0 + 32 * K_LD;
+    bf16x8_t kf[8];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp0 + ks * 16);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      const bf16_t* kp = Ks + buf * K_TILE + kb * 32 * K_LD + k_frag;
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(kp + ks * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kb], 0, 0, 0);
-      }
+    for (int ks = 0; ks < 8; ++ks) {
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[0], 0, 0, 0);
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp1 + ks * 16);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[1], 0, 0, 0);
   };
 
   // ---- phase 2: online softmax (row = this lane's query), then O^T += V^T P^T -------
   auto softmax_pv_phase = [&](int t) {
     const int buf = t & 1;
+    // V^T fragments of the first two 16-key steps are fetched now and land under the softmax
+    const bf16_t* vp = Vs + buf * V_TILE + v_frag;
+    bf16x8_t vf[8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + kk * 16 + d * 32 * V_LD);
+    __builtin_amdgcn_sched_barrier(0);
     {   // mask the padded keys of a chunk's last tile
       const int chunk = t / tiles_per_chunk;
       const int tt = t - chunk * tiles_per_chunk;
@@ -201,15 +220,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
         w[e] = pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
       pf[kk] = __builtin_bit_cast(bf16x8_t, w);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16_t* vp = Vs + buf * V_TILE + v_frag + kk * 16;
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * V_LD);
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kk], o[d], 0, 0, 0);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + (kk + 2) * 16 + d * 32 * V_LD);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 2; kk < 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(kk - 2) * 4 + d], pf[kk], o[d], 0, 0, 0);
   };
 
   if (STAGGER) {

@@ -44,14 +44,16 @@ def _close(out, ref, ulps=2.0, atol=0.0, what="", mag=None):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 384, 256), (128, 64, 64), (37, 128, 64),
                                    (4097, 1024, 1024), (2500, 3072, 512)])
-@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "bias_res"])
+@pytest.mark.parametrize("mode", ["plain", "bias", "bias_gelu", "bias_res", "bias_res_small"])
 def test_gemm(dev, M, N, K, mode):
+    force_small = mode.endswith("_small")      # 128x128 register-staged kernel at every shape
+    mode = mode.replace("_small", "")
     from actionmesh_amd import ops
     a = _randn((M, K), 1, dev).to(torch.bfloat16)
     w = _randn((N, K), 2, dev, 1.0 / math.sqrt(K)).to(torch.bfloat16)
     bias = rb(_randn((N,), 3, dev, 0.5)) if mode != "plain" else None
     res = _randn((M, N), 4, dev).to(torch.bfloat16) if mode == "bias_res" else None
-    out = ops.gemm(a, w, bias=bias, residual=res, gelu=(mode == "bias_gelu"))
+    out = ops.gemm(a, w, bias=bias, residual=res, gelu=(mode == "bias_gelu"), force_small=force_small)
     torch.cuda.synchronize()
     ref = a.float() @ w.float().T
     if bias is not None:
@@ -95,6 +97,28 @@ def test_gemm_split_a_and_row_maps(dev):
     out2 = ops.gemm(src, w2, a_map=(G, L, 1), M=frames * G)
     ref2 = rb(src.view(frames, L, 128)[:, 1:].reshape(-1, 128).float() @ w2.float().T)
     _close(out2, ref2, atol=2e-3, what="a_map rows")
+
+
+def test_gemm256_split_a_row_maps_and_tails(dev):
+    """The 256x256 DMA-staged kernel (M >= 1024, N >= 256): split A, both row maps, M/N tails."""
+    from actionmesh_amd import ops
+    frames, G, L = 30, 48, 49
+    M, N, K1, K2 = frames * G, 328, 128, 64        # M = 1440 (tail 160 of 256), N = 328 (tail)
+    a1 = _randn((frames * L, K1), 1, dev).to(torch.bfloat16)
+    a2 = _randn((frames * L, K2), 2, dev).to(torch.bfloat16)
+    w = _randn((N, K1 + K2), 3, dev, 0.07).to(torch.bfloat16)
+    bias = rb(_randn((N,), 4, dev, 0.5))
+    res = _randn((frames * L, N), 5, dev).to(torch.bfloat16)
+    dst = res.clone()
+    ops.gemm(a1, w, bias=bias, a2=a2, residual=dst, out=dst, a_map=(G, L, 1), c_map=(G, L, 1), M=M)
+    torch.cuda.synchronize()
+    cat = torch.cat([a1, a2], 1).view(frames, L, K1 + K2)[:, 1:].reshape(M, K1 + K2).float()
+    lin = rb(cat @ w.float().T + bias)
+    r3 = res.view(frames, L, N).float()
+    ref = lin.view(frames, G, N) + r3[:, 1:]
+    got = dst.view(frames, L, N)
+    _close(got[:, 1:], ref, atol=4e-3, what="gemm256 maps", mag=torch.maximum(lin.view(frames, G, N).abs(), r3[:, 1:].abs()))
+    assert torch.equal(got[:, 0], res.view(frames, L, N)[:, 0]), "row 0 of every frame must be untouched"
 
 
 def test_gemm_in_place_residual(dev):

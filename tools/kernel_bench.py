@@ -42,9 +42,11 @@ def main():
         Sq = T * L
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
-        ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=a.defer), a.reps)
         fl = 4.0 * Sq * Sq * C * B
-        print(f"self-attn  B={B} H={H} S={Sq}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        for d in (a.defer, a.defer + 100):
+            ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
+            print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({'lockstep' if d >= 100 else 'staggered'}): "
+                  f"{ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         del Q, K, Vt, out
     if "xattn" in only:
         BT = B * T
@@ -63,8 +65,11 @@ def main():
             A = rnd(R, Kk); W = rnd(Nn, Kk); out = torch.empty((R, Nn), dtype=torch.bfloat16, device=dev)
             bias = torch.randn(Nn, device=dev) if kw.get("bias") else None
             res = rnd(R, Nn) if kw.get("res") else None
-            ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out), a.reps)
-            print(f"gemm {name:13s} M={R} N={Nn} K={Kk}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            for small in (False, True):
+                ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
+                                             force_small=small), a.reps)
+                print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {'128sq-regstage' if small else '256sq-dma     '}: "
+                      f"{ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             del A, W, out, res
     if "ln" in only:
         x = rnd(R, C); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)

@@ -47,7 +47,7 @@ constexpr int K_TILE = KVBLK * K_LD;
 constexpr int V_TILE = HD * V_LD;
 constexpr int SMEM_BYTES = 2 * (K_TILE + V_TILE) * (int)sizeof(bf16_t);   // 71680
 
-template <int DEFER, bool STAGGER>
+template <int DEFER, bool STAGGER, int ABL>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int tiles_per_chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [2][64][K_LD]
@@ -95,12 +95,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     vb = p.Vt + off + (int64_t)tt * KVBLK;
   };
   auto load_k = [&](int t) {
+    if (ABL == 5 || ABL == 6) return;
     const bf16_t *kb, *vb;
     tile_base(t, kb, vb);
 #pragma unroll
     for (int i = 0; i < 2; ++i) kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + k_src_off[i]);
   };
   auto load_v = [&](int t) {
+    if (ABL == 5 || ABL == 6) return;
     const bf16_t *kb, *vb;
     tile_base(t, kb, vb);
 #pragma unroll
@@ -108,10 +110,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
       vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)v_src_row[i] * p.sk_pad + v_src_col[i]);
   };
   auto store_k = [&](int buf) {
+    if (ABL == 5 || ABL == 6) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Ks[buf * K_TILE + k_lds[i]]) = kreg[i];
   };
   auto store_v = [&](int buf) {
+    if (ABL == 5 || ABL == 6) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Vs[buf * V_TILE + v_lds[i]]) = vreg[i];
   };
@@ -137,6 +141,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     const bf16_t* kp0 = Ks + buf * K_TILE + k_frag;
     const bf16_t* kp1 = kp0 + 32 * K_LD;
     bf16x8_t kf[8];
+    if (ABL == 3) return;                      // ablation: no MFMA at all
+    if (ABL == 4 || ABL == 5) {                // ablation: MFMAs fed from registers (no LDS reads)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + 1) & 7], qf[ks], s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[(ks + 3) & 7], qf[ks], s[1], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp0 + ks * 16);
 #pragma unroll
@@ -161,6 +176,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     // V^T fragments of the first two 16-key steps are fetched now and land under the softmax
     const bf16_t* vp = Vs + buf * V_TILE + v_frag;
     bf16x8_t vf[8];
+    if (ABL == 1 || ABL == 5) {                // ablation: no softmax arithmetic (P := S)
+      bf16x8_t pq[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          w[e] = pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+        pq[kk] = __builtin_bit_cast(bf16x8_t, w);
+      }
+      l_run = 1.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const bf16x8_t a = (ABL == 5) ? qf[(kk + d) & 7]
+                                        : *reinterpret_cast<const bf16x8_t*>(vp + kk * 16 + d * 32 * V_LD);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pq[kk], o[d], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -221,6 +257,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
       pf[kk] = __builtin_bit_cast(bf16x8_t, w);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (ABL == 3) {                            // ablation: softmax only, keep P alive
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(pf[kk]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(vf[i]));
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -289,17 +332,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   }
 }
 
-template <int DEFER, bool STAGGER>
+template <int DEFER, bool STAGGER, int ABL = 0>
 int launch(const am_attn_args* a, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, STAGGER>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, STAGGER, ABL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     attr_set = true;
   }
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
-  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, STAGGER>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
+  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, STAGGER, ABL>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
                      tiles_per_chunk);
   AM_HIP(hipGetLastError());
   return AM_OK;
@@ -330,6 +373,18 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
     case 8: return launch<8, true>(a, stream);
     case 100: return launch<0, false>(a, stream);
     case 108: return launch<8, false>(a, stream);
+#ifdef AM_ATTN_ABLATIONS   // timing-only variants (wrong results by construction); tools/kernel_bench.py --ablate
+    case 1001: return launch<8, true, 1>(a, stream);
+    case 1003: return launch<8, true, 3>(a, stream);
+    case 1004: return launch<8, true, 4>(a, stream);
+    case 1005: return launch<8, true, 5>(a, stream);
+    case 1006: return launch<8, true, 6>(a, stream);
+    case 1101: return launch<8, false, 1>(a, stream);
+    case 1103: return launch<8, false, 3>(a, stream);
+    case 1104: return launch<8, false, 4>(a, stream);
+    case 1105: return launch<8, false, 5>(a, stream);
+    case 1106: return launch<8, false, 6>(a, stream);
+#endif
     default: AM_FAIL(AM_ERR_INVALID, "am_attention_bf16: defer_log2 must be 0 or 8 (got %d)", a->defer_log2);
   }
 }

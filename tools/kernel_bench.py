@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--only", default="attn,xattn,gemm,ln,post")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--defer", type=int, default=8)
+    ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
     a = ap.parse_args()
     T, N, C, H, S = (16, 4096, 1024, 8, 257) if a.shape == "headline" else (16, 2048, 2048, 16, 257)
     B, L = 2, N + 1
@@ -47,6 +48,13 @@ def main():
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({'lockstep' if d >= 100 else 'staggered'}): "
                   f"{ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if a.ablate:
+            names = {1: "no softmax math", 3: "no MFMA (softmax+LDS only)", 4: "MFMA from regs (no LDS reads)",
+                     5: "MFMA only (no LDS, no softmax, no staging)", 6: "no global loads / LDS writes"}
+            for base, lab in ((1000, "staggered"), (1100, "lockstep")):
+                for k, nm in names.items():
+                    ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=base + k), a.reps)
+                    print(f"  ablation {lab:9s} {nm:45s}: {ms:8.3f} ms  ({fl / ms / 1e9:7.1f} TF-equivalent)")
         del Q, K, Vt, out
     if "xattn" in only:
         BT = B * T

@@ -5,7 +5,8 @@
 //
 // Work decomposition: one workgroup = 8 waves = 256 query rows of one
 // (sequence, head); each wave owns 32 query rows.  Keys/values stream through
-// LDS in tiles of 64 keys, double-buffered, staged global -> VGPR -> LDS.
+// LDS in tiles of 64 keys, double-buffered, DMA'd straight from global memory
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
 //
 // MFMA formulation (v_mfma_f32_32x32x16_bf16, "swapped" so that the softmax
 // row is lane-local and P never leaves registers):
@@ -19,21 +20,24 @@
 // with keys permuted inside each group of 16 (perm16: bit2<->bit3) and the
 // matching A-operand is one contiguous 16-byte LDS read.
 //
-// Schedule (STAGGER = true): a CU holds one workgroup = two waves per SIMD
-// (wave i and wave i+4 share SIMD i).  Waves 4-7 run exactly one phase behind
-// waves 0-3 (they take one extra s_barrier before the loop, waves 0-3 one
-// after it), and every tile is two phases separated by barriers:
-//   phase 1: S^T = K Q^T (16 MFMA)          | also: LDS-write K(t+1), issue V(t+1) loads
-//   phase 2: softmax (VALU) then P.V (16 MFMA) | also: issue K(t+2) loads, LDS-write V(t+1)
-// so on every SIMD one wave's QK^T MFMAs run beside its partner's softmax
-// VALU work and are followed by the partner's P.V MFMAs: the matrix pipe is
-// never idle during a softmax.  Each half-workgroup stages its own half of
-// every K / V^T tile; the hazard analysis (which global phase may write which
-// LDS buffer) is in DESIGN.md section "attention".
+// LDS image (DMA writes are lane-linear, so the bank swizzle is applied to the
+// per-lane SOURCE address and mirrored on the read side):
+//   K tile  [64 keys][16 units of 16 B]: unit c of row r at position c ^ (r & 15)
+//   V^T tile [128 d ][ 8 units of 16 B]: unit c of row r at position c ^ ((r>>1) & 7)
+// Both give every 16-lane ds_read_b128 group 16 distinct 16-byte slots.
+//
+// Schedules (template STAGGER):
+//   false: one barrier per tile; DMA of tile t+1 issued at the top of tile t.
+//   true : waves 4-7 run one phase behind waves 0-3 (they take one extra
+//          s_barrier before the loop, waves 0-3 one after it); a tile is two
+//          phases (QK^T | softmax + P.V) separated by barriers, each half-
+//          workgroup DMAs its own half of every tile (hazards: DESIGN.md).
 //
 // Multi-GPU: K/V arrive as `nchunks` frame shards ([chunk][seq][head]...);
 // softmax is permutation-invariant over keys, so chunks are simply
 // concatenated tile streams, each with its own valid-key count.
+#include <type_traits>
+
 #include "am_common.h"
 
 namespace {
@@ -41,25 +45,27 @@ namespace {
 constexpr int QBLK = 256;          // query rows per workgroup
 constexpr int KVBLK = 64;          // keys per tile
 constexpr int HD = 128;
-constexpr int K_LD = HD + 8;       // padded K row in LDS (272 B): 16 distinct 16-B slots per lane group
-constexpr int V_LD = KVBLK + 8;    // padded V^T row in LDS (144 B)
-constexpr int K_TILE = KVBLK * K_LD;
-constexpr int V_TILE = HD * V_LD;
-constexpr int SMEM_BYTES = 2 * (K_TILE + V_TILE) * (int)sizeof(bf16_t);   // 71680
+constexpr int K_TILE_B = KVBLK * HD * 2;   // 16 KiB
+constexpr int V_TILE_B = HD * KVBLK * 2;   // 16 KiB
+constexpr int SMEM_BYTES = 2 * (K_TILE_B + V_TILE_B);   // 64 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <int DEFER, bool STAGGER, int ABL>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int tiles_per_chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);       // [2][64][K_LD]
-  bf16_t* Vs = Ks + 2 * K_TILE;                       // [2][128][V_LD]
+  unsigned char* Ks = smem;                       // [2][16 KiB]
+  unsigned char* Vs = smem + 2 * K_TILE_B;        // [2][16 KiB]
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int bh = blockIdx.y;                          // sequence * heads + head
   const int head = bh % p.heads, seq = bh / p.heads;
   const int q0 = blockIdx.x * QBLK + wave * 32;
-  const bool late = STAGGER && (__builtin_amdgcn_readfirstlane(tid) >= 256);   // waves 4-7: one phase behind
+  const bool late = STAGGER && wave >= 4;             // waves 4-7: one phase behind
 
   // ---- Q fragments (B operand): Q[q0 + l31][ks*16 + hi*8 .. +8] -------------
   bf16x8_t qf[8];
@@ -69,55 +75,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
   }
 
-  // ---- K / V^T tile staging: 1024 x 16 B each, two per thread.  With STAGGER each
-  // half-workgroup (256 threads) owns one half of every tile: c in [half*512, half*512+512).
-  int k_src_off[2], v_src_row[2], v_src_col[2], k_lds[2], v_lds[2];
+  // ---- DMA descriptors.  Unit U of a tile (16 B each, 1024 per tile) is owned by
+  // (j, wave, lane): U = j*512 + wave*64 + lane, j = 0,1 (lockstep) or, with STAGGER,
+  // each half-workgroup owns one half: U = half*512 + j*256 + (wave&3)*64 + lane.
+  int k_src[2], v_src_row[2], v_src_col[2], u_base[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = STAGGER ? ((tid >> 8) * 512 + (tid & 255) + 256 * i) : (tid + 512 * i);
-    const int krow = c >> 4, kcol = (c & 15) * 8;
-    k_src_off[i] = krow * HD + kcol;
-    k_lds[i] = krow * K_LD + kcol;
-    const int vrow = c >> 3, vcol = (c & 7) * 8;
-    v_src_row[i] = vrow;
-    v_src_col[i] = vcol;
-    v_lds[i] = vrow * V_LD + vcol;
+  for (int j = 0; j < 2; ++j) {
+    const int ub = STAGGER ? ((wave >> 2) * 512 + j * 256 + (wave & 3) * 64) : (j * 512 + wave * 64);
+    u_base[j] = ub;                                 // wave-uniform LDS unit base of this instruction
+    const int U = ub + lane;
+    const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+    k_src[j] = kr * HD + kc * 8;
+    const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+    v_src_row[j] = vr;
+    v_src_col[j] = vc * 8;
   }
   const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;     // per (seq, head)
   const int total_tiles = p.nchunks * tiles_per_chunk;
+  const bf16_t* k_base = p.K + (int64_t)bh * k_seq_stride;
+  const bf16_t* v_base = p.Vt + (int64_t)bh * k_seq_stride;
+  const bf16_t* v_lane[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) v_lane[j] = v_base + (int64_t)v_src_row[j] * p.sk_pad + v_src_col[j];
 
-  u32x4_t kreg[2], vreg[2];
-  auto tile_base = [&](int t, const bf16_t*& kb, const bf16_t*& vb) {
-    const int chunk = t / tiles_per_chunk;
-    const int tt = t - chunk * tiles_per_chunk;
-    const int64_t off = (int64_t)chunk * p.chunk_stride + (int64_t)bh * k_seq_stride;
-    kb = p.K + off + (int64_t)tt * KVBLK * HD;
-    vb = p.Vt + off + (int64_t)tt * KVBLK;
-  };
-  auto load_k = [&](int t) {
+  // tile t -> (chunk, tile in chunk) without a division per tile: the DMA cursors only move forward
+  int dk_chunk = 0, dk_tt = 0, dv_chunk = 0, dv_tt = 0;
+  auto dma_k = [&](int buf) {      // DMA the K tile at the K cursor, then advance it
     if (ABL == 5 || ABL == 6) return;
-    const bf16_t *kb, *vb;
-    tile_base(t, kb, vb);
+    const bf16_t* kb = k_base + (int64_t)dk_chunk * p.chunk_stride + (int64_t)dk_tt * KVBLK * HD;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + k_src_off[i]);
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(Ks + buf * K_TILE_B + u_base[j] * 16), 16, 0, 0);
+    if (++dk_tt == tiles_per_chunk) { dk_tt = 0; ++dk_chunk; }
   };
-  auto load_v = [&](int t) {
+  auto dma_v = [&](int buf) {
     if (ABL == 5 || ABL == 6) return;
-    const bf16_t *kb, *vb;
-    tile_base(t, kb, vb);
+    const int64_t off = (int64_t)dv_chunk * p.chunk_stride + (int64_t)dv_tt * KVBLK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      vreg[i] = *reinterpret_cast<const u32x4_t*>(vb + (int64_t)v_src_row[i] * p.sk_pad + v_src_col[i]);
-  };
-  auto store_k = [&](int buf) {
-    if (ABL == 5 || ABL == 6) return;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Ks[buf * K_TILE + k_lds[i]]) = kreg[i];
-  };
-  auto store_v = [&](int buf) {
-    if (ABL == 5 || ABL == 6) return;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(&Vs[buf * V_TILE + v_lds[i]]) = vreg[i];
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + off), (lds_ptr_t)(Vs + buf * V_TILE_B + u_base[j] * 16), 16, 0, 0);
+    if (++dv_tt == tiles_per_chunk) { dv_tt = 0; ++dv_chunk; }
   };
 
   f32x16_t o[4];
@@ -129,17 +126,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   float l_run = 0.f;         // this half-lane's partial row sum
   const float c = p.scale * 1.4426950408889634f;
 
-  const int k_frag = l31 * K_LD + hi * 8;
-  const int v_frag = l31 * V_LD + hi * 8;
+  // fragment read offsets (bytes) inside a tile
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
   f32x16_t s[2];
+  int c_tt = 0;              // compute cursor: tile index inside its chunk (for the tail mask)
 
   // ---- phase 1: S^T = K Q^T.  The 16 K fragments are read 8 deep ahead of the MFMAs that
-  // consume them (LDS latency ~100+ cycles vs 32 cycles per MFMA): 8 reads up front, then every
-  // MFMA of the first key block re-fills its fragment slot with the second block's fragment.
-  auto qk_phase = [&](int t) {
-    const int buf = t & 1;
-    const bf16_t* kp0 = Ks + buf * K_TILE + k_frag;
-    const bf16_t* kp1 = kp0 + 32 * K_LD;
+  // consume them: 8 reads up front, then every MFMA of the first key block re-fills its
+  // fragment slot with the second block's fragment.
+  auto qk_phase = [&](int buf) {
+    const unsigned char* kp0 = Ks + buf * K_TILE_B;
+    const unsigned char* kp1 = kp0 + 32 * 256;
     bf16x8_t kf[8];
     if (ABL == 3) return;                      // ablation: no MFMA at all
     if (ABL == 4 || ABL == 5) {                // ablation: MFMAs fed from registers (no LDS reads)
@@ -153,14 +154,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp0 + ks * 16);
+    for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp0 + k_off[ks]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[0], 0, 0, 0);
-      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp1 + ks * 16);
+      kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp1 + k_off[ks]);
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
     }
@@ -171,11 +172,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   };
 
   // ---- phase 2: online softmax (row = this lane's query), then O^T += V^T P^T -------
-  auto softmax_pv_phase = [&](int t) {
-    const int buf = t & 1;
+  auto softmax_pv_phase = [&](int buf) {
     // V^T fragments of the first two 16-key steps are fetched now and land under the softmax
-    const bf16_t* vp = Vs + buf * V_TILE + v_frag;
+    const unsigned char* vp = Vs + buf * V_TILE_B;
     bf16x8_t vf[8];
+    const int valid = p.sk - c_tt * KVBLK;      // wave-uniform; < 64 only on a chunk's last tile
+    if (++c_tt == tiles_per_chunk) c_tt = 0;
     if (ABL == 1 || ABL == 5) {                // ablation: no softmax arithmetic (P := S)
       bf16x8_t pq[4];
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const bf16x8_t a = (ABL == 5) ? qf[(kk + d) & 7]
-                                        : *reinterpret_cast<const bf16x8_t*>(vp + kk * 16 + d * 32 * V_LD);
+                                        : *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pq[kk], o[d], 0, 0, 0);
         }
       return;
@@ -201,21 +203,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + kk * 16 + d * 32 * V_LD);
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
     __builtin_amdgcn_sched_barrier(0);
-    {   // mask the padded keys of a chunk's last tile
-      const int chunk = t / tiles_per_chunk;
-      const int tt = t - chunk * tiles_per_chunk;
-      const int valid = p.sk - tt * KVBLK;      // wave-uniform
-      if (valid < KVBLK) {
+    if (valid < KVBLK) {     // mask the padded keys of a chunk's last tile (a real branch: rare)
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= valid) s[kb][r] = -INFINITY;
-          }
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= valid) s[kb][r] = -INFINITY;
+        }
     }
     float mx = s[0][0];
 #pragma unroll
@@ -236,16 +234,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
     }
-    float rs = 0.f;
+    float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -m_run));
-        s[kb][r] = pv;
-        rs += pv;
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c, -m_run));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r + 1], c, -m_run));
+        s[kb][r] = p0;
+        s[kb][r + 1] = p1;
+        rs0 += p0;
+        rs1 += p1;
       }
-    l_run += rs;
+    l_run += rs0 + rs1;
     // P^T fragments (B operand), straight from the S registers
     bf16x8_t pf[4];
 #pragma unroll
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
-        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + (kk + 2) * 16 + d * 32 * V_LD);
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
@@ -282,35 +283,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   };
 
   if (STAGGER) {
-    // prologue: tile 0 complete in buffer 0 (each half-workgroup brings its half), K(1) in flight
-    load_k(0);
-    load_v(0);
-    store_k(0);
-    store_v(0);
-    if (total_tiles > 1) load_k(1);
+    // prologue: tile 0 in buffer 0 (each half-workgroup DMAs its half)
+    dma_k(0);
+    dma_v(0);
     if (late) __syncthreads();                  // waves 4-7 start one phase late
     for (int t = 0; t < total_tiles; ++t) {
-      __syncthreads();                          // ---- phase 1 of tile t
-      if (t + 1 < total_tiles) load_v(t + 1);
-      qk_phase(t);
-      if (t + 1 < total_tiles) store_k((t + 1) & 1);
+      __syncthreads();                          // ---- phase 1 of tile t   (drains + publishes DMAs)
+      if (t + 1 < total_tiles) dma_k((t + 1) & 1);
+      qk_phase(t & 1);
       __syncthreads();                          // ---- phase 2 of tile t
-      if (t + 2 < total_tiles) load_k(t + 2);
-      softmax_pv_phase(t);
-      if (t + 1 < total_tiles) store_v((t + 1) & 1);
+      if (t + 1 < total_tiles) dma_v((t + 1) & 1);
+      softmax_pv_phase(t & 1);
     }
     if (!late) __syncthreads();                 // balance the barrier count
   } else {
-    load_k(0);
-    load_v(0);
-    store_k(0);
-    store_v(0);
+    dma_k(0);
+    dma_v(0);
     for (int t = 0; t < total_tiles; ++t) {
-      __syncthreads();
-      if (t + 1 < total_tiles) { load_k(t + 1); load_v(t + 1); }
-      qk_phase(t);
-      softmax_pv_phase(t);
-      if (t + 1 < total_tiles) { store_k((t + 1) & 1); store_v((t + 1) & 1); }
+      __syncthreads();                          // tile t landed; everyone is done with the other buffer
+      if (t + 1 < total_tiles) { dma_k((t + 1) & 1); dma_v((t + 1) & 1); }
+      qk_phase(t & 1);
+      softmax_pv_phase(t & 1);
     }
   }
 
@@ -332,6 +325,283 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   }
 }
 
+
+// ===========================================================================
+// Software-pipelined schedule (default).  Measurements on MI355X (tools/ubench,
+// tools/kernel_bench.py --ablate) show that the two waves sharing a SIMD do not
+// hide each other's softmax: time(full) ~= time(MFMA only) + time(everything
+// else).  What does hide VALU work is issuing it from the SAME wave inside the
+// 32-cycle shadow of its own MFMAs.  So each wave keeps two score tiles live and
+// every tile iteration is two MFMA streams with the softmax of the neighbouring
+// tile threaded through their gaps:
+//   phase A: S(t+1) = K(t+1) Q^T   (16 MFMA)  ||  finish softmax(t): exp2, row sums, bf16 P(t)
+//   phase B: O += V(t)^T P(t)      (16 MFMA)  ||  start softmax(t+1): mask, row max, rescale decision
+// A pending rescale (rare with the deferred threshold) is applied after the
+// P.V MFMAs of phase B, i.e. when everything accumulated so far is at the old
+// max (the ordering hazard of deferred rescaling).  One barrier per tile; the
+// K DMA runs two tiles ahead, the V^T DMA one tile ahead.
+// ===========================================================================
+template <int DEFER>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, int tiles_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                       // [2][16 KiB]
+  unsigned char* Vs = smem + 2 * K_TILE_B;        // [2][16 KiB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int head = bh % p.heads, seq = bh / p.heads;
+  const int q0 = blockIdx.x * QBLK + wave * 32;
+
+  bf16x8_t qf[8];
+  {
+    const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + l31) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+  }
+
+  int k_src[2], u_base[2];
+  const bf16_t* v_lane[2];
+  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+  const bf16_t* k_base = p.K + (int64_t)bh * k_seq_stride;
+  {
+    const bf16_t* v_base = p.Vt + (int64_t)bh * k_seq_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u_base[j] = j * 512 + wave * 64;
+      const int U = u_base[j] + lane;
+      const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+      k_src[j] = kr * HD + kc * 8;
+      const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+      v_lane[j] = v_base + (int64_t)vr * p.sk_pad + vc * 8;
+    }
+  }
+  const int total_tiles = p.nchunks * tiles_per_chunk;
+  int dk_chunk = 0, dk_tt = 0, dv_chunk = 0, dv_tt = 0;
+  auto dma_k = [&](int buf) {
+    const bf16_t* kb = k_base + (int64_t)dk_chunk * p.chunk_stride + (int64_t)dk_tt * KVBLK * HD;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(Ks + buf * K_TILE_B + u_base[j] * 16), 16, 0, 0);
+    if (++dk_tt == tiles_per_chunk) { dk_tt = 0; ++dk_chunk; }
+  };
+  auto dma_v = [&](int buf) {
+    const int64_t off = (int64_t)dv_chunk * p.chunk_stride + (int64_t)dv_tt * KVBLK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + off), (lds_ptr_t)(Vs + buf * V_TILE_B + u_base[j] * 16), 16, 0, 0);
+    if (++dv_tt == tiles_per_chunk) { dv_tt = 0; ++dv_chunk; }
+  };
+
+  f32x16_t o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * 1.4426950408889634f;
+
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+
+  int c_tt = 0;                 // tile-in-chunk cursor of the finish step (row-sum tail correction)
+  bool pend = false;            // rescale decided by start_softmax, applied after the next P.V
+  float pend_alpha = 1.f, pend_m = 0.f;
+
+  // ---- start softmax of a raw score tile: row max, rescale decision.  Straight-line (no
+  // branches) so that the scheduler can thread it through the P.V MFMAs.  There is no key mask:
+  // padded key rows of K are zero (am_head_post guarantees it), so their score is exactly 0 -
+  // harmless in the running max - and their V^T columns are zero, so they add nothing to O;
+  // only the row sum needs a correction, applied in the tile's finish step (tail_fix).
+  auto start_softmax = [&](f32x16_t (&sx)[2]) {
+    float mx = sx[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[kb][r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_tile = mx * c;
+    pend = (DEFER > 0) ? !__all(m_tile - m_run <= (float)DEFER) : true;
+    pend_m = fmaxf(m_run, m_tile);
+    pend_alpha = __builtin_amdgcn_exp2f(m_run - pend_m);
+  };
+  // row-sum correction for a chunk's partial last tile: each padded key contributed
+  // exp2(0*c - m_run) to this lane's partial sum
+  auto tail_fix = [&]() {
+    const int valid = p.sk - c_tt * KVBLK;      // valid keys of the tile being finished (wave-uniform)
+    if (++c_tt == tiles_per_chunk) c_tt = 0;
+    if (valid < KVBLK) {
+      int cnt = 0;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cnt += min(4, max(0, kb * 32 + 8 * g + 4 * hi + 4 - valid));
+      l_run -= (float)cnt * __builtin_amdgcn_exp2f(-m_run);
+    }
+  };
+  auto apply_rescale = [&]() {
+    if (pend) {
+      m_run = pend_m;
+      l_run *= pend_alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= pend_alpha;
+      pend = false;
+    }
+  };
+  // ---- finish softmax: P = exp2(S c - m), row sums, bf16 B-operand fragments ---------------
+  auto finish_softmax = [&](f32x16_t (&sx)[2], bf16x8_t (&pf)[4]) {
+    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kb][r], c, -m_run));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kb][r + 1], c, -m_run));
+        sx[kb][r] = p0;
+        sx[kb][r + 1] = p1;
+        rs0 += p0;
+        rs1 += p1;
+      }
+    l_run += rs0 + rs1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = pack_bf2(sx[kk >> 1][(kk & 1) * 8 + 2 * e], sx[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+      pf[kk] = __builtin_bit_cast(bf16x8_t, w);
+    }
+  };
+  // fragment reads run PF (=4) MFMAs ahead of their consumer
+  constexpr int PF = 4;
+  auto qk_mfma = [&](int buf, f32x16_t (&sx)[2]) {
+    const unsigned char* kp0 = Ks + buf * K_TILE_B;
+    bf16x8_t kf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) kf[i] = *reinterpret_cast<const bf16x8_t*>(kp0 + k_off[i]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sx[0][r] = 0.f; sx[1][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {          // i = kb*8 + ks
+      const int kb = i >> 3, ks = i & 7;
+      sx[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % PF], qf[ks], sx[kb], 0, 0, 0);
+      if (i + PF < 16) {
+        const int n = i + PF;
+        kf[i % PF] = *reinterpret_cast<const bf16x8_t*>(kp0 + (n >> 3) * 32 * 256 + k_off[n & 7]);
+      }
+    }
+  };
+  auto pv_mfma = [&](int buf, const bf16x8_t (&pf)[4]) {
+    const unsigned char* vp = Vs + buf * V_TILE_B;
+    bf16x8_t vf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) vf[i] = *reinterpret_cast<const bf16x8_t*>(vp + (i & 3) * 32 * 128 + v_off[i >> 2]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {          // i = kk*4 + d
+      const int kk = i >> 2, d = i & 3;
+      o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % PF], pf[kk], o[d], 0, 0, 0);
+      if (i + PF < 16) {
+        const int n = i + PF;
+        vf[i % PF] = *reinterpret_cast<const bf16x8_t*>(vp + (n & 3) * 32 * 128 + v_off[n >> 2]);
+      }
+    }
+  };
+
+  // one tile iteration: sc = scores of tile t (started), sn = scores of tile t+1 (to compute)
+  auto iteration = [&](int t, f32x16_t (&sc)[2], f32x16_t (&sn)[2]) {
+    __syncthreads();                                  // K(t+1), V(t) landed; old buffers free
+    if (t + 2 < total_tiles) dma_k(t & 1);
+    if (t + 1 < total_tiles) dma_v((t + 1) & 1);
+    bf16x8_t pf[4];
+    const bool has_next = t + 1 < total_tiles;
+    // ---- phase A: QK^T(t+1) || finish softmax(t) --------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) {
+      qk_mfma((t + 1) & 1, sn);
+      finish_softmax(sc, pf);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read (4 ahead)
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);            // 5 VALU
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);            // 2 TRANS (v_exp)
+      }
+    } else {
+      finish_softmax(sc, pf);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tail_fix();
+    // ---- phase B: P.V(t) || start softmax(t+1) --------------------------------------------
+    pv_mfma(t & 1, pf);
+    if (has_next) {
+      start_softmax(sn);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read (4 ahead)
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);            // 3 VALU
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    apply_rescale();                                  // after ALL of P.V(t): everything is at the old max
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------
+  f32x16_t sa[2], sb[2];
+  dma_k(0);
+  dma_v(0);
+  if (total_tiles > 1) dma_k(1);
+  __syncthreads();
+  qk_mfma(0, sa);
+  start_softmax(sa);
+  apply_rescale();
+  for (int t = 0; t < total_tiles; t += 2) {
+    iteration(t, sa, sb);
+    if (t + 1 < total_tiles) iteration(t + 1, sb, sa);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.sq) {
+    bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
+      }
+  }
+}
+
+template <int DEFER>
+int launch_pipe(const am_attn_args* a, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_pipe_kernel<DEFER>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    attr_set = true;
+  }
+  const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
+  dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
+  hipLaunchKernelGGL((attn_fwd_pipe_kernel<DEFER>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a, tiles_per_chunk);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 template <int DEFER, bool STAGGER, int ABL = 0>
 int launch(const am_attn_args* a, void* stream) {
   static bool attr_set = false;
@@ -350,8 +620,9 @@ int launch(const am_attn_args* a, void* stream) {
 
 }  // namespace
 
-// defer_log2: 0 or 8 = deferred-rescale threshold; add 100 to select the un-staggered
-// (lockstep) schedule, kept for A/B measurements (tools/kernel_bench.py --variant).
+// defer_log2: 0 or 8 = deferred-rescale threshold (software-pipelined schedule, the default);
+// +100 = staggered half-workgroup schedule, +200 = plain lockstep schedule (both kept for A/B
+// measurements, tools/kernel_bench.py).
 extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_attention_bf16: null args");
   AM_CHECK(a->Q && a->K && a->Vt && a->O, "am_attention_bf16: null operand");
@@ -369,21 +640,23 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
   switch (a->defer_log2) {
-    case 0: return launch<0, true>(a, stream);
-    case 8: return launch<8, true>(a, stream);
-    case 100: return launch<0, false>(a, stream);
-    case 108: return launch<8, false>(a, stream);
+    case 0: return launch_pipe<0>(a, stream);
+    case 8: return launch_pipe<8>(a, stream);
+    case 200: return launch<0, false>(a, stream);
+    case 208: return launch<8, false>(a, stream);
+    case 100: return launch<0, true>(a, stream);
+    case 108: return launch<8, true>(a, stream);
 #ifdef AM_ATTN_ABLATIONS   // timing-only variants (wrong results by construction); tools/kernel_bench.py --ablate
-    case 1001: return launch<8, true, 1>(a, stream);
-    case 1003: return launch<8, true, 3>(a, stream);
-    case 1004: return launch<8, true, 4>(a, stream);
-    case 1005: return launch<8, true, 5>(a, stream);
-    case 1006: return launch<8, true, 6>(a, stream);
-    case 1101: return launch<8, false, 1>(a, stream);
-    case 1103: return launch<8, false, 3>(a, stream);
-    case 1104: return launch<8, false, 4>(a, stream);
-    case 1105: return launch<8, false, 5>(a, stream);
-    case 1106: return launch<8, false, 6>(a, stream);
+    case 1001: return launch<8, false, 1>(a, stream);
+    case 1003: return launch<8, false, 3>(a, stream);
+    case 1004: return launch<8, false, 4>(a, stream);
+    case 1005: return launch<8, false, 5>(a, stream);
+    case 1006: return launch<8, false, 6>(a, stream);
+    case 1101: return launch<8, true, 1>(a, stream);
+    case 1103: return launch<8, true, 3>(a, stream);
+    case 1104: return launch<8, true, 4>(a, stream);
+    case 1105: return launch<8, true, 5>(a, stream);
+    case 1106: return launch<8, true, 6>(a, stream);
 #endif
     default: AM_FAIL(AM_ERR_INVALID, "am_attention_bf16: defer_log2 must be 0 or 8 (got %d)", a->defer_log2);
   }

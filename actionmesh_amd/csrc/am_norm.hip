@@ -110,7 +110,15 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
 #pragma unroll
     for (int pass = 0; pass < HP_TOK / 16; ++pass) {
       const int s = s0 + pass * 16 + tok_in_pass;
-      if (s >= p.seq_len) continue;     // uniform per 16-lane group
+      if (s >= p.seq_len) {             // uniform per 16-lane group
+        // K rows of the padded tail of the last key tile must be zero: the attention kernel
+        // relies on score(padded key) == 0 instead of masking (am_attention.hip, tail_fix)
+        if (kind == 1 && s < s_pad) {
+          bf16_t* dst = out + (((int64_t)sidx * p.heads + head) * s_pad + s) * 128 + sub * 8;
+          *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        continue;
+      }
       const int64_t row = (int64_t)sidx * p.seq_len + s;
       const u32x4_t u = *reinterpret_cast<const u32x4_t*>(p.X + row * p.ldx + col);
       float v[8];

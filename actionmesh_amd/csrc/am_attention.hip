@@ -354,54 +354,61 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, i
   const int bh = blockIdx.y;
   const int head = bh % p.heads, seq = bh / p.heads;
   const int q0 = blockIdx.x * QBLK + wave * 32;
+  const float c = p.scale * 1.4426950408889634f;
 
-  bf16x8_t qf[8];
+  bf16x8_t qf[8];                                 // pre-scaled to log2 units (see the lean kernel)
   {
     const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + l31) * HD + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
-  }
-
-  int k_src[2], u_base[2];
-  const bf16_t* v_lane[2];
-  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
-  const bf16_t* k_base = p.K + (int64_t)bh * k_seq_stride;
-  {
-    const bf16_t* v_base = p.Vt + (int64_t)bh * k_seq_stride;
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
+      u32x4_t sc;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      u_base[j] = j * 512 + wave * 64;
-      const int U = u_base[j] + lane;
-      const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
-      k_src[j] = kr * HD + kc * 8;
-      const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
-      v_lane[j] = v_base + (int64_t)vr * p.sk_pad + vc * 8;
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf2(bflo(raw[e]) * c, bfhi(raw[e]) * c);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, sc);
     }
   }
+
+  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+  const bf16_t* k_lane[2];
+  const bf16_t* v_lane[2];
+  int u_byte[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    u_byte[j] = (j * 512 + wave * 64) * 16;
+    const int U = j * 512 + wave * 64 + lane;
+    const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+    k_lane[j] = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;
+    const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+    v_lane[j] = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;
+  }
   const int total_tiles = p.nchunks * tiles_per_chunk;
-  int dk_chunk = 0, dk_tt = 0, dv_chunk = 0, dv_tt = 0;
+  int dk_tt = 0, dv_tt = 0;
+  int64_t dk_chunk = 0, dv_chunk = 0;
   auto dma_k = [&](int buf) {
-    const bf16_t* kb = k_base + (int64_t)dk_chunk * p.chunk_stride + (int64_t)dk_tt * KVBLK * HD;
+    const int64_t ko = dk_chunk + (int64_t)dk_tt * (KVBLK * HD);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(Ks + buf * K_TILE_B + u_base[j] * 16), 16, 0, 0);
-    if (++dk_tt == tiles_per_chunk) { dk_tt = 0; ++dk_chunk; }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(k_lane[j] + ko), (lds_ptr_t)(Ks + buf * K_TILE_B + u_byte[j]), 16, 0, 0);
+    if (++dk_tt == tiles_per_chunk) { dk_tt = 0; dk_chunk += p.chunk_stride; }
   };
   auto dma_v = [&](int buf) {
-    const int64_t off = (int64_t)dv_chunk * p.chunk_stride + (int64_t)dv_tt * KVBLK;
+    const int64_t vo = dv_chunk + (int64_t)dv_tt * KVBLK;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + off), (lds_ptr_t)(Vs + buf * V_TILE_B + u_base[j] * 16), 16, 0, 0);
-    if (++dv_tt == tiles_per_chunk) { dv_tt = 0; ++dv_chunk; }
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + vo), (lds_ptr_t)(Vs + buf * V_TILE_B + u_byte[j]), 16, 0, 0);
+    if (++dv_tt == tiles_per_chunk) { dv_tt = 0; dv_chunk += p.chunk_stride; }
   };
 
-  f32x16_t o[4];
+  f32x16_t o[4], zero16;
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int r = 0; r < 16; ++r) {
+    zero16[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = p.scale * 1.4426950408889634f;
+    for (int d = 0; d < 4; ++d) o[d][r] = 0.f;
+  }
+  float m_run = 0.f, l_run = 0.f;
+  bool first = true;
 
   int k_off[8], v_off[4];
 #pragma unroll
@@ -411,32 +418,75 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, i
 
   int c_tt = 0;                 // tile-in-chunk cursor of the finish step (row-sum tail correction)
   bool pend = false;            // rescale decided by start_softmax, applied after the next P.V
-  float pend_alpha = 1.f, pend_m = 0.f;
+  float pend_delta = 0.f;
 
-  // ---- start softmax of a raw score tile: row max, rescale decision.  Straight-line (no
-  // branches) so that the scheduler can thread it through the P.V MFMAs.  There is no key mask:
-  // padded key rows of K are zero (am_head_post guarantees it), so their score is exactly 0 -
-  // harmless in the running max - and their V^T columns are zero, so they add nothing to O;
-  // only the row sum needs a correction, applied in the tile's finish step (tail_fix).
+  auto max3 = [](float a, float b, float cc) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(cc));
+    return d;
+  };
+  // ---- start softmax of a raw score tile: row max + rescale decision (straight-line) ----------
   auto start_softmax = [&](f32x16_t (&sx)[2]) {
-    float mx = sx[0][0];
+    float mxa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(sx[0][i], sx[1][i], sx[0][i + 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], sx[1][i + 4], sx[0][i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], sx[1][i + 8], sx[0][i + 12]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], sx[1][i + 12], mxa[i]);
+    float mx = max3(mxa[0], mxa[1], max3(mxa[2], mxa[3], mxa[3]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+    }
+    mx -= m_run;
+    pend = first || !__all(mx <= (float)DEFER);
+    pend_delta = first ? mx : fmaxf(mx, 0.f);
+  };
+  auto apply_rescale = [&]() {
+    if (pend) {
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-pend_delta);
+      first = false;
+      m_run += pend_delta;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      pend = false;
+    }
+  };
+  // ---- finish softmax: P = exp2(S - m), row sums, bf16 B-operand fragments ----------------------
+  auto finish_softmax = [&](f32x16_t (&sx)[2], bf16x8_t (&pf)[4]) {
+    const f32x2_t m2 = {m_run, m_run};
+    f32x2_t rsa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsa[i] = f32x2_t{0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[kb][r]);
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_t x = f32x2_t{sx[kb][r], sx[kb][r + 1]} - m2;
+        const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        sx[kb][r] = pp[0];
+        sx[kb][r + 1] = pp[1];
+        rsa[(r >> 1) & 3] += pp;
+      }
+    const f32x2_t rs = (rsa[0] + rsa[1]) + (rsa[2] + rsa[3]);
+    l_run += rs[0] + rs[1];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = pack_bf2(sx[kk >> 1][(kk & 1) * 8 + 2 * e], sx[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+      pf[kk] = __builtin_bit_cast(bf16x8_t, w);
     }
-    const float m_tile = mx * c;
-    pend = (DEFER > 0) ? !__all(m_tile - m_run <= (float)DEFER) : true;
-    pend_m = fmaxf(m_run, m_tile);
-    pend_alpha = __builtin_amdgcn_exp2f(m_run - pend_m);
   };
-  // row-sum correction for a chunk's partial last tile: each padded key contributed
-  // exp2(0*c - m_run) to this lane's partial sum
-  auto tail_fix = [&]() {
-    const int valid = p.sk - c_tt * KVBLK;      // valid keys of the tile being finished (wave-uniform)
+  auto tail_fix = [&]() {       // partial last tile of a chunk (see the lean kernel)
+    const int valid = p.sk - c_tt * KVBLK;
     if (++c_tt == tiles_per_chunk) c_tt = 0;
     if (valid < KVBLK) {
       int cnt = 0;
@@ -447,54 +497,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, i
       l_run -= (float)cnt * __builtin_amdgcn_exp2f(-m_run);
     }
   };
-  auto apply_rescale = [&]() {
-    if (pend) {
-      m_run = pend_m;
-      l_run *= pend_alpha;
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= pend_alpha;
-      pend = false;
-    }
-  };
-  // ---- finish softmax: P = exp2(S c - m), row sums, bf16 B-operand fragments ---------------
-  auto finish_softmax = [&](f32x16_t (&sx)[2], bf16x8_t (&pf)[4]) {
-    float rs0 = 0.f, rs1 = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kb][r], c, -m_run));
-        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kb][r + 1], c, -m_run));
-        sx[kb][r] = p0;
-        sx[kb][r + 1] = p1;
-        rs0 += p0;
-        rs1 += p1;
-      }
-    l_run += rs0 + rs1;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      u32x4_t w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        w[e] = pack_bf2(sx[kk >> 1][(kk & 1) * 8 + 2 * e], sx[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
-      pf[kk] = __builtin_bit_cast(bf16x8_t, w);
-    }
-  };
-  // fragment reads run PF (=4) MFMAs ahead of their consumer
-  constexpr int PF = 4;
+  constexpr int PF = 4;         // fragment reads run 4 MFMAs ahead of their consumer
   auto qk_mfma = [&](int buf, f32x16_t (&sx)[2]) {
     const unsigned char* kp0 = Ks + buf * K_TILE_B;
     bf16x8_t kf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) kf[i] = *reinterpret_cast<const bf16x8_t*>(kp0 + k_off[i]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { sx[0][r] = 0.f; sx[1][r] = 0.f; }
-#pragma unroll
     for (int i = 0; i < 16; ++i) {          // i = kb*8 + ks
       const int kb = i >> 3, ks = i & 7;
-      sx[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % PF], qf[ks], sx[kb], 0, 0, 0);
+      sx[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % PF], qf[ks], ks == 0 ? zero16 : sx[kb], 0, 0, 0);
       if (i + PF < 16) {
         const int n = i + PF;
         kf[i % PF] = *reinterpret_cast<const bf16x8_t*>(kp0 + (n >> 3) * 32 * 256 + k_off[n & 7]);
@@ -531,10 +543,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, i
       finish_softmax(sc, pf);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // 1 MFMA
         if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read (4 ahead)
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);            // 5 VALU
-        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);            // 2 TRANS (v_exp)
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);             // 3 VALU (pk sub / pk add / cvt)
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);             // 2 TRANS (v_exp)
       }
     } else {
       finish_softmax(sc, pf);
@@ -547,9 +559,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(am_attn_args p, i
       start_softmax(sn);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // 1 MFMA
         if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // 1 DS read (4 ahead)
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);            // 3 VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);             // 2 VALU
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -602,6 +614,299 @@ int launch_pipe(const am_attn_args* a, void* stream) {
   return AM_OK;
 }
 
+
+// ===========================================================================
+// "Lean" schedule (default).  Measured on MI355X (tools/ubench, kernel_bench
+// --ablate): with MFMAs in flight a SIMD retires roughly one instruction per
+// ~6 cycles in total, so the kernel time is ~max(32 cyc x MFMAs, 6 cyc x ALL
+// instructions): the attention loop is instruction-issue-bound, and neither
+// staggering the waves nor threading the softmax through the MFMA gaps helps
+// while there are ~10 non-MFMA instructions per MFMA.  This variant therefore
+// minimises the instruction count per tile:
+//   * Q is pre-multiplied by scale*log2(e) once (in registers, re-rounded to
+//     bf16), so scores are born in log2 units: no per-element multiply;
+//   * the running max is subtracted two elements at a time (v_pk_add_f32);
+//   * no key mask: padded K rows / V^T columns are zero (am_head_post), the row
+//     sum of a partial tile is corrected once per tile (tail_fix);
+//   * row sums with packed adds, row max with v_max3, cross-half exchange with
+//     v_permlane32_swap (no LDS round trip);
+//   * tile loop unrolled by two so LDS addresses are immediates; one DMA cursor.
+// Per element and lane: 1 exp + 0.5 sub + 0.5 add + 0.5 cvt + 0.5 max.
+// ===========================================================================
+template <int DEFER, bool PROF = false, int LA = 0>   // LA: timing-only ablations (tools/kernel_bench.py)
+__global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, int tiles_per_chunk,
+                                                              unsigned long long* prof = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // PROF: waves of block (0,0) record s_memtime at 6 points of tiles 64..71 -> prof[wave][tile][6]
+  int prof_t = 0;
+  auto stamp = [&](int slot) {
+    if (PROF) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && prof_t >= 64 && prof_t < 72) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long tk = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) prof[((threadIdx.x >> 6) * 8 + (prof_t - 64)) * 6 + slot] = tk;
+      }
+    }
+  };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int head = bh % p.heads, seq = bh / p.heads;
+  const int q0 = blockIdx.x * QBLK + wave * 32;
+  const float c = p.scale * 1.4426950408889634f;
+
+  // ---- Q fragments, pre-scaled to log2 units ---------------------------------------------
+  bf16x8_t qf[8];
+  {
+    const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + l31) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
+      u32x4_t sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf2(bflo(raw[e]) * c, bfhi(raw[e]) * c);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, sc);
+    }
+  }
+
+  // ---- DMA descriptors (unit U = j*512 + wave*64 + lane of each 1024-unit tile) -------------
+  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+  const bf16_t* k_lane[2];
+  const bf16_t* v_lane[2];
+  int u_byte[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    u_byte[j] = (j * 512 + wave * 64) * 16;
+    const int U = j * 512 + wave * 64 + lane;
+    const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+    k_lane[j] = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;
+    const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+    v_lane[j] = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;
+  }
+  const int total_tiles = p.nchunks * tiles_per_chunk;
+  int d_tt = 0;                       // DMA cursor: tile inside its chunk
+  int64_t d_chunk = 0;                // element offset of the cursor's chunk
+  auto dma_tile = [&](int buf) {      // K and V^T tile at the cursor -> LDS buffer `buf`; advance
+    const int64_t ko = d_chunk + (int64_t)d_tt * (KVBLK * HD);
+    const int64_t vo = d_chunk + (int64_t)d_tt * KVBLK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(k_lane[j] + ko), (lds_ptr_t)(smem + buf * K_TILE_B + u_byte[j]), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + vo),
+                                       (lds_ptr_t)(smem + 2 * K_TILE_B + buf * V_TILE_B + u_byte[j]), 16, 0, 0);
+    if (++d_tt == tiles_per_chunk) { d_tt = 0; d_chunk += p.chunk_stride; }
+  };
+
+  f32x16_t o[4], zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    zero16[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d][r] = 0.f;
+  }
+  float m_run = 0.f;       // running max (log2 units); defined by the first tile
+  float l_run = 0.f;       // this half-lane's partial row sum
+  bool first = true;
+
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  int c_tt = 0;            // compute cursor (tail correction)
+
+  auto tile = [&](int buf, bool more) {
+    stamp(0);                                 // before the barrier
+    __syncthreads();                          // tile landed (drains the DMA); other buffer is free
+    stamp(1);                                 // barrier passed
+    if (more) dma_tile(buf ^ 1);
+    const unsigned char* kp = smem + buf * K_TILE_B;
+    const unsigned char* vp = smem + 2 * K_TILE_B + buf * V_TILE_B;
+    // ---- S = K Q'^T (log2 units) ----------------------------------------------------------------
+    f32x16_t s[2];
+    {
+      bf16x8_t kf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + k_off[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0], 0, 0, 0);
+        kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * 256 + k_off[ks]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1], 0, 0, 0);
+    }
+    if (PROF) { asm volatile("" ::"v"(s[0]), "v"(s[1])); stamp(2); }   // QK^T issued + drained
+    // V^T fragments of the first two 16-key steps: in flight under the softmax
+    bf16x8_t vf[8];
+    if (LA != 5) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
+    }
+    // ---- row max of S' (= how far this tile's max is above the running max) ----------------------
+    // (four independent v_max3 chains: the softmax section is VALU-latency-bound, not
+    // throughput-bound - in-kernel s_memtime stamps, tools/attn_profile.py)
+    // v_max3 through inline asm: fmaxf() on MFMA outputs makes hipcc emit a canonicalising
+    // v_max x,x,x per operand (32 extra VALU per tile)
+    auto max3 = [](float a, float b, float cc) {
+      float d;
+      asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(cc));
+      return d;
+    };
+    float mxa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(s[0][i], s[1][i], s[0][i + 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 4], s[0][i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 8], s[0][i + 12]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 12], mxa[i]);
+    float mx = max3(mxa[0], mxa[1], max3(mxa[2], mxa[3], mxa[3]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+    }
+    if (LA == 2 || LA == 6) mx = s[0][0];         // ablation: no row max
+    mx -= m_run;                                  // how far this tile's max is above the running max
+    if (first || !__all(mx <= (float)DEFER)) {   // rare after the first tile (deferred rescale)
+      const float delta = first ? mx : fmaxf(mx, 0.f);
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      first = false;
+      m_run += delta;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    // ---- P = exp2(S - m_run), row sums, bf16 B-operand fragments ------------------------------------
+    const f32x2_t m2 = {m_run, m_run};
+    f32x2_t rsa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsa[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2_t x = f32x2_t{s[kb][r], s[kb][r + 1]} - m2;      // v_pk_add_f32
+        const f32x2_t pp = (LA == 1 || LA == 6) ? x : f32x2_t{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        s[kb][r] = pp[0];
+        s[kb][r + 1] = pp[1];
+        if (LA != 3 && LA != 6) rsa[(r >> 1) & 3] += pp;
+      }
+    {
+      const f32x2_t rs = (rsa[0] + rsa[1]) + (rsa[2] + rsa[3]);
+      l_run += rs[0] + rs[1];
+    }
+    {   // partial last tile of a chunk: remove the padded keys' exp2(0 - m_run) from the row sum
+      const int valid = p.sk - c_tt * KVBLK;
+      if (++c_tt == tiles_per_chunk) c_tt = 0;
+      if (valid < KVBLK) {
+        int cnt = 0;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) cnt += min(4, max(0, kb * 32 + 8 * g + 4 * hi + 4 - valid));
+        l_run -= (float)cnt * __builtin_amdgcn_exp2f(-m_run);
+      }
+    }
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = (LA == 4 || LA == 6) ? __float_as_uint(s[kk >> 1][(kk & 1) * 8 + 2 * e])
+                                    : pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+      pf[kk] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    if (LA == 5) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
+    }
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+    if (PROF) { asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3])); stamp(3); }   // softmax done
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 2; kk < 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(kk - 2) * 4 + d], pf[kk], o[d], 0, 0, 0);
+    if (PROF) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+      stamp(4);                               // P.V drained
+      ++prof_t;
+    }
+  };
+
+  dma_tile(0);
+  for (int t = 0; t < total_tiles; t += 2) {
+    tile(0, t + 1 < total_tiles);
+    if (t + 1 < total_tiles) tile(1, t + 2 < total_tiles);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.sq) {
+    bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
+      }
+  }
+}
+
+template <int DEFER, int LA = 0>
+int launch_lean(const am_attn_args* a, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lean_kernel<DEFER, false, LA>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    attr_set = true;
+  }
+  const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
+  dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
+  hipLaunchKernelGGL((attn_fwd_lean_kernel<DEFER, false, LA>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
+                     tiles_per_chunk, (unsigned long long*)nullptr);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 template <int DEFER, bool STAGGER, int ABL = 0>
 int launch(const am_attn_args* a, void* stream) {
   static bool attr_set = false;
@@ -619,6 +924,20 @@ int launch(const am_attn_args* a, void* stream) {
 }
 
 }  // namespace
+
+#ifdef AM_ATTN_ABLATIONS
+// per-phase s_memtime stamps of the lean kernel (block (0,0), 8 waves x tiles 64..71 x 6 slots)
+extern "C" int am_attention_profile(const am_attn_args* a, unsigned long long* prof_dev, void* stream) {
+  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lean_kernel<8, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
+  dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
+  hipLaunchKernelGGL((attn_fwd_lean_kernel<8, true>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
+                     tiles_per_chunk, prof_dev);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+#endif
 
 // defer_log2: 0 or 8 = deferred-rescale threshold (software-pipelined schedule, the default);
 // +100 = staggered half-workgroup schedule, +200 = plain lockstep schedule (both kept for A/B
@@ -640,13 +959,21 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
   switch (a->defer_log2) {
-    case 0: return launch_pipe<0>(a, stream);
-    case 8: return launch_pipe<8>(a, stream);
+    case 0: return launch_lean<0>(a, stream);
+    case 8: return launch_lean<8>(a, stream);
+    case 300: return launch_pipe<0>(a, stream);
+    case 308: return launch_pipe<8>(a, stream);
     case 200: return launch<0, false>(a, stream);
     case 208: return launch<8, false>(a, stream);
     case 100: return launch<0, true>(a, stream);
     case 108: return launch<8, true>(a, stream);
 #ifdef AM_ATTN_ABLATIONS   // timing-only variants (wrong results by construction); tools/kernel_bench.py --ablate
+    case 2001: return launch_lean<8, 1>(a, stream);
+    case 2002: return launch_lean<8, 2>(a, stream);
+    case 2003: return launch_lean<8, 3>(a, stream);
+    case 2004: return launch_lean<8, 4>(a, stream);
+    case 2005: return launch_lean<8, 5>(a, stream);
+    case 2006: return launch_lean<8, 6>(a, stream);
     case 1001: return launch<8, false, 1>(a, stream);
     case 1003: return launch<8, false, 3>(a, stream);
     case 1004: return launch<8, false, 4>(a, stream);

@@ -44,10 +44,14 @@ def main():
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
         fl = 4.0 * Sq * Sq * C * B
-        for d, nm in ((a.defer, "pipelined"), (a.defer + 200, "lockstep"), (a.defer + 100, "staggered")):
+        for d, nm in ((a.defer, "lean"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"), (a.defer + 100, "staggered")):
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:9s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         if a.ablate:
+            for k, nm in {1: "no exp", 2: "no row max", 3: "no row sum", 4: "no cvt", 5: "V frags not prefetched",
+                          6: "no softmax VALU at all"}.items():
+                ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=2000 + k), a.reps)
+                print(f"  lean ablation {nm:30s}: {ms:8.3f} ms  ({fl / ms / 1e9:7.1f} TF-equivalent)")
             names = {1: "no softmax math", 3: "no MFMA (softmax+LDS only)", 4: "MFMA from regs (no LDS reads)",
                      5: "MFMA only (no LDS, no softmax, no staging)", 6: "no global loads / LDS writes"}
             for base, lab in ((1000, "lockstep"), (1100, "staggered")):

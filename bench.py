@@ -101,9 +101,16 @@ def attention_roofline(T, N, H, dev, world=1, reps=3):
     sec = e0.elapsed_time(e1) / 1e3 / reps
     flops = 4.0 * Sq * (Sq * world) * (H * 128) * B
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel (inflated self-attention, 1 launch = 1 layer)",
+    # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/gpu_profile.sh); the
+    # committed summary is quoted when it was measured on this launch shape, otherwise null.
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_attention_traffic.json")
+    if world == 1 and (T, N, H) == (16, 4096, 8) and os.path.exists(tj):
+        with open(tj) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+    return {"bound": "mfma", "kernel": "attn_fwd_lean_kernel (inflated self-attention, 1 launch = 1 layer)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "launch_ms": round(sec * 1e3, 3), "flops_per_launch": flops}
 
 

@@ -144,3 +144,47 @@ def test_fails_loudly_without_hip_path(dev):
     with pytest.raises(RuntimeError):
         m.to(dev).forward(torch.zeros(2, 2, 4, 64, device=dev), torch.zeros(2, 2, 3, 64, device=dev),
                           torch.zeros(2, 2, device=dev), torch.zeros(2, device=dev))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_two_rank_frame_sharding_emulated_on_one_gpu(dev, golden_dir, name):
+    """The N>1 data path on real hardware without a second GPU: two engines (rank 0 / rank 1 of a
+    world of 2) on the same device run the phase protocol; the K/V all-gather is emulated by copying
+    each rank's chunk into the other's gather buffer.  Must match the unsharded forward."""
+    from actionmesh_amd import ClassifierFreeGuidance
+    from actionmesh_amd.denoiser import HipEngine, masked_time, rope_tables_host
+    from actionmesh_amd.sharding import FrameShardPlan
+    g, cfg, sd, model, t = _setup(name, golden_dir, dev)
+    if t["init_latent"].shape[1] % 2:
+        pytest.skip("odd frame count")
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    B, T, N, _ = x_in.shape
+    S = c_in.shape[2]
+    tt = [float(g["fwd_t"])] * B
+    ref, _ = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), torch.tensor(tt, device=dev), m_in.to(dev), None)
+    t_bt = masked_time(tt, m_in, B, T)
+    cos, sin = rope_tables_host(f_in, 128)
+    engines, plans = [], []
+    for r in range(2):
+        plan = FrameShardPlan(T, 2, r)
+        e = HipEngine(model.hyper_params(), sd, dev, B, plan.frames_local, N, S, world=2, rank=r)
+        e.set_context(plan.slice_frames(c_in.to(dev)), cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64),
+                      sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64))
+        tl = plan.frames_local
+        e.begin(plan.slice_frames(x_in.to(dev)), [t_bt[b * T + r * tl + j] for b in range(B) for j in range(tl)])
+        engines.append(e); plans.append(plan)
+    for i in range(cfg.num_layers):
+        for e in engines:
+            e.layer_pre(i)
+        if engines[0].is_inflated(i):          # emulated all-gather: rank r contributes chunk r
+            (k0, v0), (k1, v1) = engines[0].kv_buffers(), engines[1].kv_buffers()
+            k0[1].copy_(k1[1]); v0[1].copy_(v1[1]); k1[0].copy_(k0[0]); v1[0].copy_(v0[0])
+        for e in engines:
+            e.layer_post(i)
+    v = torch.cat([e.end() for e in engines], dim=1)
+    torch.cuda.synchronize()
+    r = rel(v, ref)
+    print(f"{name}: 2-rank emulated vs unsharded rel-L2 {r:.3e}")
+    assert r < 5e-3
+    assert rel(v.float().cpu(), torch.from_numpy(g["fwd_velocity_fp32"])) < 2e-2

@@ -633,9 +633,15 @@ int launch_pipe(const am_attn_args* a, void* stream) {
 //   * tile loop unrolled by two so LDS addresses are immediates; one DMA cursor.
 // Per element and lane: 1 exp + 0.5 sub + 0.5 add + 0.5 cvt + 0.5 max.
 // ===========================================================================
-template <int DEFER, bool PROF = false, int LA = 0>   // LA: timing-only ablations (tools/kernel_bench.py)
+// SPLIT: the workgroup handles only the key tiles [z*nt/Z, (z+1)*nt/Z) (z = blockIdx.z) of query block
+// `qblk_base + blockIdx.x` and writes un-normalised fp32 (O, m, l) partials for attn_combine_kernel.
+// Used for the short last query block of every sequence: seq = T*(N+1) is 256*k + a few rows for every
+// reference shape, and a 16-row block would otherwise cost a full extra round of workgroups (6 %).
+constexpr int PART_LD = HD + 4;   // floats per partial row: O[128], m, l, pad (keeps rows 16-byte aligned)
+template <int DEFER, bool PROF = false, int LA = 0, bool SPLIT = false>   // LA: timing-only ablations
 __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, int tiles_per_chunk,
-                                                              unsigned long long* prof = nullptr) {
+                                                              unsigned long long* prof = nullptr,
+                                                              int qblk_base = 0, float* part = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // PROF: waves of block (0,0) record s_memtime at 6 points of tiles 64..71 -> prof[wave][tile][6]
   int prof_t = 0;
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, i
   const int l31 = lane & 31, hi = lane >> 5;
   const int bh = blockIdx.y;
   const int head = bh % p.heads, seq = bh / p.heads;
-  const int q0 = blockIdx.x * QBLK + wave * 32;
+  const int q0 = (qblk_base + blockIdx.x) * QBLK + wave * 32;
   const float c = p.scale * 1.4426950408889634f;
 
   // ---- Q fragments, pre-scaled to log2 units ---------------------------------------------
@@ -686,9 +692,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, i
     const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
     v_lane[j] = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;
   }
-  const int total_tiles = p.nchunks * tiles_per_chunk;
-  int d_tt = 0;                       // DMA cursor: tile inside its chunk
-  int64_t d_chunk = 0;                // element offset of the cursor's chunk
+  const int all_tiles = p.nchunks * tiles_per_chunk;
+  const int t_begin = SPLIT ? (int)((int64_t)blockIdx.z * all_tiles / gridDim.z) : 0;
+  const int t_end = SPLIT ? (int)((int64_t)(blockIdx.z + 1) * all_tiles / gridDim.z) : all_tiles;
+  const int total_tiles = t_end - t_begin;
+  int d_tt = t_begin % tiles_per_chunk;                                   // DMA cursor: tile inside its chunk
+  int64_t d_chunk = (int64_t)(t_begin / tiles_per_chunk) * p.chunk_stride; // element offset of the cursor's chunk
   auto dma_tile = [&](int buf) {      // K and V^T tile at the cursor -> LDS buffer `buf`; advance
     const int64_t ko = d_chunk + (int64_t)d_tt * (KVBLK * HD);
     const int64_t vo = d_chunk + (int64_t)d_tt * KVBLK;
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, i
   for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
-  int c_tt = 0;            // compute cursor (tail correction)
+  int c_tt = t_begin % tiles_per_chunk;   // compute cursor (tail correction)
 
   auto tile = [&](int buf, bool more) {
     stamp(0);                                 // before the barrier
@@ -875,8 +884,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, i
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
+  if (SPLIT) {
+    if (q < p.sq) {
+      float* pp = part + ((((int64_t)bh * gridDim.z + blockIdx.z) * QBLK) + (q - qblk_base * QBLK)) * PART_LD;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4_t*>(pp + d * 32 + 8 * g + 4 * hi) =
+              f32x4_t{o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
+      if (hi == 0) { pp[HD] = m_run; pp[HD + 1] = l_tot; }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_tot;
   if (q < p.sq) {
     bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
 #pragma unroll
@@ -891,18 +913,62 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_lean_kernel(am_attn_args p, i
   }
 }
 
+// merge the Z partial results of the split (tail) query block: O = sum_z 2^(m_z - m) O_z / sum_z 2^(m_z - m) l_z
+__global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const float* __restrict__ part, int Z,
+                                                           int qblk_base, int rows) {
+  const int bh = blockIdx.y, row = blockIdx.x;          // one 128-thread block per (sequence*head, tail row)
+  if (row >= rows) return;
+  const int d = threadIdx.x;
+  const float* base = part + ((int64_t)bh * Z * QBLK + row) * PART_LD;
+  float m = -INFINITY;
+  for (int z = 0; z < Z; ++z) m = fmaxf(m, base[(int64_t)z * QBLK * PART_LD + HD]);
+  float acc = 0.f, l = 0.f;
+  for (int z = 0; z < Z; ++z) {
+    const float* pz = base + (int64_t)z * QBLK * PART_LD;
+    const float w = __builtin_amdgcn_exp2f(pz[HD] - m);
+    acc += w * pz[d];
+    l += w * pz[HD + 1];
+  }
+  const int head = bh % p.heads, seq = bh / p.heads;
+  p.O[((int64_t)seq * p.sq + qblk_base * QBLK + row) * p.ldo + head * HD + d] = f2bf(acc / l);
+}
+
 template <int DEFER, int LA = 0>
 int launch_lean(const am_attn_args* a, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lean_kernel<DEFER, false, LA>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lean_kernel<DEFER, false, LA, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_lean_kernel<DEFER, false, LA, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     attr_set = true;
   }
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
-  dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
-  hipLaunchKernelGGL((attn_fwd_lean_kernel<DEFER, false, LA>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
-                     tiles_per_chunk, (unsigned long long*)nullptr);
+  const int all_tiles = tiles_per_chunk * a->nchunks;
+  const int nblk = ceil_div(a->sq, QBLK);
+  const int bh = a->nseq * a->heads;
+  const int tail_rows = a->sq - (nblk - 1) * QBLK;
+  // split the short last query block over the key range when it would otherwise add a round
+  constexpr int Z = 16;
+  static float* part = nullptr;
+  static size_t part_elems = 0;
+  const size_t need = (size_t)bh * Z * QBLK * PART_LD;
+  const bool split = LA == 0 && nblk >= 9 && tail_rows <= 128 && all_tiles >= 4 * Z && need * sizeof(float) <= (256u << 20);
+  if (split && part_elems < need) {     // library-owned scratch, grown on demand (never on a captured stream)
+    if (part) AM_HIP(hipFree(part));
+    part = nullptr; part_elems = 0;
+    AM_HIP(hipMalloc(reinterpret_cast<void**>(&part), need * sizeof(float)));
+    part_elems = need;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(split ? nblk - 1 : nblk, bh);
+  hipLaunchKernelGGL((attn_fwd_lean_kernel<DEFER, false, LA, false>), grid, dim3(512), SMEM_BYTES, st, *a,
+                     tiles_per_chunk, (unsigned long long*)nullptr, 0, (float*)nullptr);
+  if (split) {
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<DEFER, false, LA, true>), dim3(1, bh, Z), dim3(512), SMEM_BYTES, st, *a,
+                       tiles_per_chunk, (unsigned long long*)nullptr, nblk - 1, part);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(tail_rows, bh), dim3(128), 0, st, *a, part, Z, nblk - 1, tail_rows);
+  }
   AM_HIP(hipGetLastError());
   return AM_OK;
 }
@@ -933,7 +999,7 @@ extern "C" int am_attention_profile(const am_attn_args* a, unsigned long long* p
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   dim3 grid(ceil_div(a->sq, QBLK), a->nseq * a->heads);
   hipLaunchKernelGGL((attn_fwd_lean_kernel<8, true>), grid, dim3(512), SMEM_BYTES, (hipStream_t)stream, *a,
-                     tiles_per_chunk, prof_dev);
+                     tiles_per_chunk, prof_dev, 0, (float*)nullptr);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

@@ -63,8 +63,21 @@ __device__ inline uint32_t pack_bf2(float lo, float hi) {
 __device__ inline float bflo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
 __device__ inline float bfhi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
 
-// exact-erf GELU (F.gelu(approximate="none"))
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (F.gelu(approximate="none")).  erfc(|x|/sqrt2) by Abramowitz-Stegun 7.1.26 on the hardware
+// rcp / exp2: |error| <= 3.3e-7 absolute, <= 1.7e-4 relative for |gelu| > 1e-3 - an order of magnitude
+// below the bf16 rounding applied to the result - at ~14 instructions instead of ~50 for libm erff
+// (the GELU epilogue was 40 % of the ff1 GEMM's time).
+__device__ inline float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = 1.061405429f;
+  p = __builtin_fmaf(p, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  return x >= 0.f ? __builtin_fmaf(-x, half_erfc, x) : x * half_erfc;
+}
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

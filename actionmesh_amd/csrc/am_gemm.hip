@@ -31,7 +31,7 @@ __device__ inline int64_t map_row(int r, int G, int gs, int off) {
   return (int64_t)g * gs + off + (r - g * G);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n, int m_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Bs = As + 2 * TILE_ELEMS;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
     tm = first_m + in_g % gm;
     tn = in_g / gm;
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = m_base + tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -212,7 +212,7 @@ constexpr int SMEM2_BYTES = 4 * T2_BYTES;      // A,B x 2 buffers = 128 KiB (epi
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n, int m_base) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int nb = tiles_m * tiles_n;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
     tm = first_m + in_g % gm;
     tn = in_g / gm;
   }
-  const int m0 = tm * B2, n0 = tn * B2;
+  const int m0 = m_base + tm * B2, n0 = tn * B2;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -401,13 +401,22 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
   const bool big = !force_small && args.N >= 256 && args.M >= 1024;
   if (big) {
-    const int tiles_m = ceil_div(args.M, B2), tiles_n = ceil_div(args.N, B2);
+    // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
+    // frame): a last 256-row tile holding a few rows would cost a whole extra round of workgroups.
+    // The remainder rows go to the 128x128 kernel in a second, tiny launch instead.
+    const int rem = args.M % B2;
+    const int m_main = (rem != 0 && rem <= 128 && args.M > 8 * B2) ? args.M - rem : args.M;
+    const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
     hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
-                       (hipStream_t)stream, args, tiles_m, tiles_n);
+                       (hipStream_t)stream, args, tiles_m, tiles_n, 0);
+    if (m_main < args.M) {
+      const int tn = ceil_div(args.N, BN);
+      hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
+    }
   } else {
     const int tiles_m = ceil_div(args.M, BM), tiles_n = ceil_div(args.N, BN);
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), SMEM_BYTES,
-                       (hipStream_t)stream, args, tiles_m, tiles_n);
+                       (hipStream_t)stream, args, tiles_m, tiles_n, 0);
   }
   AM_HIP(hipGetLastError());
   return AM_OK;

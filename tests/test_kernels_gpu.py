@@ -237,7 +237,9 @@ def _sdpa_ref(q, k, v):
 
 @pytest.mark.parametrize("nseq,H,sq,sk,nchunks", [(1, 2, 300, 300, 1), (2, 2, 196, 196, 1), (5, 2, 49, 9, 1),
                                                   (3, 2, 70, 17, 1), (1, 1, 1000, 64, 1), (2, 2, 196, 196, 2),
-                                                  (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1)])
+                                                  (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1),
+                                                  # short last query block -> split-KV tail path (+ chunks)
+                                                  (1, 2, 2320, 4200, 1), (2, 1, 2305, 4224, 2), (1, 1, 2432, 4097, 1)])
 @pytest.mark.parametrize("defer", [0, 8])
 def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     from actionmesh_amd import ops

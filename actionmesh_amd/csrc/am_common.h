@@ -79,6 +79,15 @@ __device__ inline float gelu_erf(float x) {
   return x >= 0.f ? __builtin_fmaf(-x, half_erfc, x) : x * half_erfc;
 }
 
+// Barrier that publishes LDS-DMA (global_load_lds) data: the DMA is a pending VMEM op of the issuing
+// wave, and hipcc does not reliably emit the vmcnt wait in front of s_barrier on every loop path
+// (observed: missing on a loop back-edge when a DMA sits under a wave-uniform branch), so the wait is
+// explicit.  Every wave drains its own DMAs, then the barrier makes all of them visible.
+__device__ inline void dma_drain_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
 
   const int nk = p.K / BK;
   dma_tile(0, 0);
-  __syncthreads();                   // drains the DMA (vmcnt(0)) and publishes it
+  dma_drain_barrier();               // tile 0 landed and is visible
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) dma_tile(kt + 1, buf ^ 1);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();                 // next tile landed; everyone is done with `buf`
+    dma_drain_barrier();             // next tile landed; everyone is done with `buf`
   }
 
   // ---- epilogue -------------------------------------------------------------------------

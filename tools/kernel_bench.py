@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--defer", type=int, default=8)
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
+    ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
     a = ap.parse_args()
     T, N, C, H, S = (16, 4096, 1024, 8, 257) if a.shape == "headline" else (16, 2048, 2048, 16, 257)
     B, L = 2, N + 1
@@ -44,7 +45,10 @@ def main():
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
         fl = 4.0 * Sq * Sq * C * B
-        for d, nm in ((a.defer, "lean"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"), (a.defer + 100, "staggered")):
+        for d, nm in ((a.defer, "product"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
+                      (a.defer + 100, "staggered")):
+            if d >= 100 and not a.variants:
+                continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:9s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         if a.ablate:

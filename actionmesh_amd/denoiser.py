@@ -178,9 +178,11 @@ class HipEngine:
 class HipDenoiser(nn.Module):
     """Drop-in replacement of ActionMeshDenoiser (see module docstring).
 
-    `process_group`: when given (world > 1) the frames of each call are sharded across the
-    group's ranks (one process per GPU) and the K/V all-gather runs on RCCL; every rank
-    passes the full (B, T, ...) tensors and receives the full velocity, like the reference.
+    `process_group`: when given (world > 1) each call is sharded across the group's ranks (one
+    process per GPU): the CFG branches first (`cfg_parallel`, when the batch and the world are
+    even), then the frames; the K/V all-gather of the inflated layers runs on RCCL inside each
+    frame group.  Every rank passes the full (B, T, ...) tensors and receives the full velocity,
+    like the reference.
     """
 
     def __init__(self, num_tokens_nominal: int = 2048, temporal_context_size: int = 16,
@@ -188,7 +190,8 @@ class HipDenoiser(nn.Module):
                  width: int = 2048, mlp_ratio: float = 4.0, cross_attention_dim: int = 1024,
                  inflated_layers: Optional[Sequence[int]] = None, clear_autocast: bool = True,
                  compile_blocks: bool = False, compile_mode: str = "default",
-                 process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8):
+                 process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8,
+                 cfg_parallel: bool = True):
         super().__init__()
         if width != num_attention_heads * HEAD_DIM:
             raise ValueError("HipDenoiser supports head_dim 128 only (width = heads * 128), as the reference ships")
@@ -205,6 +208,8 @@ class HipDenoiser(nn.Module):
         self.inflated_layers = tuple(range(num_layers)) if inflated_layers is None else tuple(inflated_layers)
         self.attn_defer_log2 = attn_defer_log2
         self.process_group = process_group
+        self.cfg_parallel = cfg_parallel
+        self._frame_groups: Dict[int, List] = {}     # cfg_groups -> [ProcessGroup per CFG branch]
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
         self._host_sd: Optional[Dict[str, torch.Tensor]] = None
         self._engine: Optional[HipEngine] = None
@@ -244,33 +249,47 @@ class HipDenoiser(nn.Module):
         return model
 
     # ---- engine management ---------------------------------------------------------------
-    def _plan(self, T: int) -> FrameShardPlan:
+    def _plan(self, T: int, B: int = 1) -> FrameShardPlan:
         if self.process_group is None:
-            return FrameShardPlan(T, 1, 0)
-        return FrameShardPlan(T, dist.get_world_size(self.process_group), dist.get_rank(self.process_group))
+            return FrameShardPlan(T, 1, 0, B, 1)
+        world = dist.get_world_size(self.process_group)
+        rank = dist.get_rank(self.process_group)
+        groups = 2 if (self.cfg_parallel and world % 2 == 0 and B % 2 == 0) else 1
+        return FrameShardPlan(T, world, rank, B, groups)
+
+    def _frame_group(self, plan: FrameShardPlan):
+        """Process group of the ranks that share this rank's CFG branch (created collectively once)."""
+        if plan.cfg_groups == 1:
+            return self.process_group
+        if plan.cfg_groups not in self._frame_groups:
+            base = dist.get_process_group_ranks(self.process_group)
+            self._frame_groups[plan.cfg_groups] = [
+                dist.new_group([base[r] for r in plan.frame_group_ranks(g)]) for g in range(plan.cfg_groups)]
+        return self._frame_groups[plan.cfg_groups][plan.cfg_rank]
 
     def _ensure_engine(self, B: int, T_local: int, N: int, S: int, plan: FrameShardPlan) -> HipEngine:
         if self._host_sd is None:
             raise RuntimeError("HipDenoiser: no weights loaded (load_state_dict / from_pretrained first)")
         e = self._engine
-        if e is not None and e.device == self.device and e.fits(B, T_local, N, S) and e.world == plan.world:
+        if e is not None and e.device == self.device and e.fits(B, T_local, N, S) and e.world == plan.frame_world \
+                and e.rank == plan.frame_rank:
             return e
         if e is not None:
             e.close()
         self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
-                                 world=plan.world, rank=plan.rank, attn_defer_log2=self.attn_defer_log2)
+                                 world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2)
         self._window = None
         return self._engine
 
     def bind_window(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int) -> WindowCache:
         """Build the step-invariant state for one window: RoPE table and cross-attention K/V."""
         B, T, S, _ = context.shape
-        plan = self._plan(T)
-        e = self._ensure_engine(B, plan.frames_local, n_tokens, S, plan)
-        cos, sin = rope_tables_host(framestep, HEAD_DIM)
-        cos = cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, HEAD_DIM // 2)
-        sin = sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, HEAD_DIM // 2)
-        e.set_context(plan.slice_frames(context), cos, sin)
+        plan = self._plan(T, B)
+        e = self._ensure_engine(plan.batch_local, plan.frames_local, n_tokens, S, plan)
+        cos, sin = rope_tables_host(framestep, HEAD_DIM)        # from the FULL window's framesteps
+        cos = plan.slice_local(cos.view(B, T, -1)).reshape(-1, HEAD_DIM // 2)
+        sin = plan.slice_local(sin.view(B, T, -1)).reshape(-1, HEAD_DIM // 2)
+        e.set_context(plan.slice_local(context), cos, sin)
         self._generation += 1
         self._window = WindowCache(self._generation)
         return self._window
@@ -278,15 +297,17 @@ class HipDenoiser(nn.Module):
     def forward_host_time(self, hidden_states: torch.Tensor, t_bt: List[float]) -> torch.Tensor:
         """Forward with the masked per-(b,t) diffusion times already on the host."""
         B, T, N, _ = hidden_states.shape
-        plan = self._plan(T)
+        plan = self._plan(T, B)
         e = self._engine
         if e is None or self._window is None:
             raise RuntimeError("HipDenoiser: bind_window() must precede forward_host_time()")
         if plan.world == 1:
             return e.forward(hidden_states, t_bt)
-        tl = plan.frames_local
-        t_local = [t_bt[b * T + plan.rank * tl + j] for b in range(B) for j in range(tl)]
-        v_local = sharded_forward(e, plan, self.process_group, plan.slice_frames(hidden_states), t_local)
+        x_local, t_local = plan.slice_local(hidden_states), plan.local_times(t_bt)
+        if plan.frame_world == 1:                       # pure CFG split: no K/V exchange at all
+            v_local = e.forward(x_local, t_local)
+        else:
+            v_local = sharded_forward(e, plan, self._frame_group(plan), x_local, t_local)
         return gather_frames(v_local, plan, self.process_group)
 
     def forward(self, hidden_states: torch.Tensor, context: torch.Tensor, framestep: torch.Tensor,

@@ -26,31 +26,75 @@ import torch.distributed as dist
 
 @dataclass(frozen=True)
 class FrameShardPlan:
+    """Which slice of a (B, T, ...) CFG batch a rank owns.
+
+    `cfg_groups` > 1 additionally splits the CFG batch: the guidance branches are independent
+    denoiser evaluations (the reference can even run them one by one, scheduler.py:150-170), so
+    with P ranks and 2 branches, ranks [0, P/2) take branch 0 and ranks [P/2, P) branch 1, and
+    the K/V all-gather only spans the P/2 ranks that share a branch (half the peers, half the
+    bytes; none at all for P = 2)."""
     n_frames: int
     world: int
     rank: int
+    batch: int = 1
+    cfg_groups: int = 1
 
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
             raise ValueError(f"bad rank {self.rank} / world {self.world}")
-        if self.n_frames % self.world != 0:
+        if self.cfg_groups < 1 or self.world % self.cfg_groups or self.batch % self.cfg_groups:
+            raise ValueError(f"cfg_groups={self.cfg_groups} must divide world={self.world} and batch={self.batch}")
+        if self.n_frames % self.frame_world != 0:
             raise ValueError(
-                f"{self.n_frames} frames do not divide over {self.world} ranks "
-                "(the reference window is 16 frames: use 1, 2, 4, 8 or 16 GPUs)")
+                f"{self.n_frames} frames do not divide over {self.frame_world} frame shards "
+                "(the reference window is 16 frames: use 1, 2, 4, 8 or 16 ranks per CFG branch)")
+
+    @property
+    def frame_world(self) -> int:          # ranks sharing one CFG group = frame shards
+        return self.world // self.cfg_groups
+
+    @property
+    def frame_rank(self) -> int:
+        return self.rank % self.frame_world
+
+    @property
+    def cfg_rank(self) -> int:
+        return self.rank // self.frame_world
 
     @property
     def frames_local(self) -> int:
-        return self.n_frames // self.world
+        return self.n_frames // self.frame_world
+
+    @property
+    def batch_local(self) -> int:
+        return self.batch // self.cfg_groups
 
     @property
     def frame_slice(self) -> slice:
-        return slice(self.rank * self.frames_local, (self.rank + 1) * self.frames_local)
+        return slice(self.frame_rank * self.frames_local, (self.frame_rank + 1) * self.frames_local)
+
+    @property
+    def batch_slice(self) -> slice:
+        return slice(self.cfg_rank * self.batch_local, (self.cfg_rank + 1) * self.batch_local)
+
+    def frame_group_ranks(self, cfg_rank: int) -> List[int]:
+        return [cfg_rank * self.frame_world + r for r in range(self.frame_world)]
 
     def slice_frames(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
-        """Local frames of a (B, T, ...) tensor (contiguous copy)."""
+        """Local frames of a (B, T, ...) tensor (contiguous copy); the batch is left alone."""
         idx = [slice(None)] * x.dim()
         idx[dim] = self.frame_slice
         return x[tuple(idx)].contiguous()
+
+    def slice_local(self, x: torch.Tensor) -> torch.Tensor:
+        """This rank's (batch rows, frames) block of a (B, T, ...) tensor (contiguous copy)."""
+        return x[self.batch_slice, self.frame_slice].contiguous()
+
+    def local_times(self, t_bt: List[float]) -> List[float]:
+        """(b t)-ordered per-frame values -> this rank's (b_local t_local)-ordered values."""
+        T, tl = self.n_frames, self.frames_local
+        b0, f0 = self.cfg_rank * self.batch_local, self.frame_rank * tl
+        return [t_bt[(b0 + b) * T + f0 + j] for b in range(self.batch_local) for j in range(tl)]
 
 
 class Engine(Protocol):
@@ -66,21 +110,22 @@ class Engine(Protocol):
 
 def exchange_kv(kv: Tuple[torch.Tensor, torch.Tensor], plan: FrameShardPlan,
                 group: Optional[dist.ProcessGroup]) -> None:
-    """All-gather the K and V^T shards in place.  `kv` tensors are (world, chunk)
-    views; rank r has written row r."""
+    """All-gather the K and V^T shards in place over this rank's frame group.  `kv` tensors are
+    (frame_world, chunk) views; frame shard r has written row r."""
     for buf in kv:
-        assert buf.shape[0] == plan.world and buf.is_contiguous()
+        assert buf.shape[0] == plan.frame_world and buf.is_contiguous()
         # flat views: accepted by both RCCL and gloo; input aliases its slot of the output
-        dist.all_gather_into_tensor(buf.view(-1), buf[plan.rank].view(-1), group=group)
+        dist.all_gather_into_tensor(buf.view(-1), buf[plan.frame_rank].view(-1), group=group)
 
 
 def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
                     x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
-    """One denoiser forward over this rank's frames; returns the local velocity."""
+    """One denoiser forward over this rank's (batch rows, frames); returns the local velocity.
+    `group` = the frame group of this rank (ranks that share its CFG branch)."""
     engine.begin(x_local, t_bt_local)
     for i in range(engine.num_layers):
         engine.layer_pre(i)
-        if plan.world > 1 and engine.is_inflated(i):
+        if plan.frame_world > 1 and engine.is_inflated(i):
             exchange_kv(engine.kv_buffers(), plan, group)
         engine.layer_post(i)
     return engine.end()
@@ -88,9 +133,12 @@ def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.P
 
 def gather_frames(v_local: torch.Tensor, plan: FrameShardPlan,
                   group: Optional[dist.ProcessGroup]) -> torch.Tensor:
-    """(B, T_local, ...) on every rank -> (B, T, ...) on every rank."""
+    """(B_local, T_local, ...) on every rank -> (B, T, ...) on every rank (`group` = all ranks).
+    Rank g*frame_world + r holds batch block g, frame shard r."""
     if plan.world == 1:
         return v_local
     parts = [torch.empty_like(v_local) for _ in range(plan.world)]
     dist.all_gather(parts, v_local.contiguous(), group=group)
-    return torch.cat(parts, dim=1)
+    fw = plan.frame_world
+    rows = [torch.cat(parts[g * fw:(g + 1) * fw], dim=1) for g in range(plan.cfg_groups)]
+    return torch.cat(rows, dim=0)

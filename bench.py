@@ -82,24 +82,26 @@ def attention_roofline(T, N, H, dev, world=1, reps=3):
     against all T frames of keys; algorithmic flops per launch = 4 * (T*L/world) * (T*L) * (H*128) * B
     (SURVEY.md 8(d))."""
     from actionmesh_amd import ops
-    B, L = 2, N + 1
-    Sq = (T // world) * L            # local query rows == keys per chunk
+    groups = 2 if world % 2 == 0 else 1          # CFG branches split first (sharding.FrameShardPlan)
+    fw = world // groups                         # frame shards per branch = key chunks
+    B, L = 2 // groups, N + 1
+    Sq = (T // fw) * L               # local query rows == keys per chunk
     sq_pad, sk_pad = ops.round_up(Sq, 256), ops.round_up(Sq, 64)
     g = torch.Generator(device=dev).manual_seed(0)
     Q = torch.randn((B, H, sq_pad, 128), device=dev, generator=g).to(torch.bfloat16)
-    K = torch.randn((world, B, H, sk_pad, 128), device=dev, generator=g).to(torch.bfloat16)
-    Vt = torch.randn((world, B, H, 128, sk_pad), device=dev, generator=g).to(torch.bfloat16)
+    K = torch.randn((fw, B, H, sk_pad, 128), device=dev, generator=g).to(torch.bfloat16)
+    Vt = torch.randn((fw, B, H, 128, sk_pad), device=dev, generator=g).to(torch.bfloat16)
     out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=dev)
-    ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=world)
+    ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=fw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=world)
+        ops.attention(Q, K, Vt, Sq, Sq, out=out, nchunks=fw)
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / reps
-    flops = 4.0 * Sq * (Sq * world) * (H * 128) * B
+    flops = 4.0 * Sq * (Sq * fw) * (H * 128) * B
     ach = flops / sec / 1e12
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/gpu_profile.sh); the
     # committed summary is quoted when it was measured on this launch shape, otherwise null.
@@ -108,7 +110,7 @@ def attention_roofline(T, N, H, dev, world=1, reps=3):
     if world == 1 and (T, N, H) == (16, 4096, 8) and os.path.exists(tj):
         with open(tj) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "attn_fwd_lean_kernel (inflated self-attention, 1 launch = 1 layer)",
+    return {"bound": "mfma", "kernel": "attn_fwd_kernel (inflated self-attention, 1 launch = 1 layer on this rank)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "launch_ms": round(sec * 1e3, 3), "flops_per_launch": flops}
@@ -233,7 +235,8 @@ def main():
         "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
                                f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
                                "random-init weights, seeded N(0,1) latents/context resident in HBM",
-                   "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"cfg-branch x{2 if world % 2 == 0 else 1} * frame-shard x{world // (2 if world % 2 == 0 else 1)}"),
                    "step_flops": step_flops},
         "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
         "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),

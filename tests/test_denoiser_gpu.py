@@ -188,3 +188,31 @@ def test_two_rank_frame_sharding_emulated_on_one_gpu(dev, golden_dir, name):
     print(f"{name}: 2-rank emulated vs unsharded rel-L2 {r:.3e}")
     assert r < 5e-3
     assert rel(v.float().cpu(), torch.from_numpy(g["fwd_velocity_fp32"])) < 2e-2
+
+
+def test_cfg_parallel_emulated_on_one_gpu(dev, golden_dir):
+    """P = 2 splits the two CFG branches across ranks (no K/V exchange): each 'rank' is an engine
+    with one batch row and all frames; stacking their velocities must reproduce the batched forward."""
+    from actionmesh_amd import ClassifierFreeGuidance
+    from actionmesh_amd.denoiser import HipEngine, masked_time, rope_tables_host
+    from actionmesh_amd.sharding import FrameShardPlan
+    g, cfg, sd, model, t = _setup("tiny_inflated", golden_dir, dev)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    B, T, N, _ = x_in.shape
+    S = c_in.shape[2]
+    tt = [float(g["fwd_t"])] * B
+    ref, _ = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), torch.tensor(tt, device=dev), m_in.to(dev), None)
+    t_bt = masked_time(tt, m_in, B, T)
+    cos, sin = rope_tables_host(f_in, 128)
+    outs = []
+    for r in range(2):
+        plan = FrameShardPlan(T, 2, r, B, 2)
+        assert plan.frame_world == 1 and plan.batch_local == 1
+        e = HipEngine(model.hyper_params(), sd, dev, 1, T, N, S, world=1, rank=0)
+        e.set_context(plan.slice_local(c_in.to(dev)), plan.slice_local(cos.view(B, T, -1)).reshape(-1, 64),
+                      plan.slice_local(sin.view(B, T, -1)).reshape(-1, 64))
+        outs.append(e.forward(plan.slice_local(x_in.to(dev)), plan.local_times(t_bt)))
+    v = torch.cat(outs, dim=0)
+    torch.cuda.synchronize()
+    assert rel(v, ref) < 2e-3

@@ -124,6 +124,17 @@ def test_frame_shard_plan():
         A.FrameShardPlan(16, 3, 0)
     with pytest.raises(ValueError):
         A.FrameShardPlan(16, 4, 4)
+    # CFG-parallel x frame shards: rank = cfg_rank * frame_world + frame_rank
+    p = A.FrameShardPlan(16, 8, 6, batch=2, cfg_groups=2)
+    assert (p.frame_world, p.frame_rank, p.cfg_rank, p.frames_local, p.batch_local) == (4, 2, 1, 4, 1)
+    assert p.frame_group_ranks(1) == [4, 5, 6, 7]
+    x = torch.arange(2 * 16 * 3).view(2, 16, 3)
+    assert torch.equal(p.slice_local(x), x[1:2, 8:12])
+    assert p.local_times(list(range(32))) == [16 + 8, 16 + 9, 16 + 10, 16 + 11]
+    p2 = A.FrameShardPlan(16, 2, 1, batch=2, cfg_groups=2)
+    assert p2.frame_world == 1 and p2.frames_local == 16 and p2.batch_slice == slice(1, 2)
+    with pytest.raises(ValueError):
+        A.FrameShardPlan(16, 4, 0, batch=3, cfg_groups=2)
 
 
 def test_perm16_is_an_involution_matching_the_mfma_layout():

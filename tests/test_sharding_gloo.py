@@ -28,8 +28,8 @@ class OracleEngine:
         self.cos, self.sin = cos_local, sin_local
         Tl, L, C = plan.frames_local, N + 1, cfg.width
         self.chunk = B * Tl * L * C
-        self.k = torch.zeros(plan.world, self.chunk)
-        self.v = torch.zeros(plan.world, self.chunk)
+        self.k = torch.zeros(plan.frame_world, self.chunk)
+        self.v = torch.zeros(plan.frame_world, self.chunk)
 
     def is_inflated(self, i):
         return i in self.cfg.inflated_layers
@@ -65,7 +65,7 @@ class OracleEngine:
         q = O.apply_rope(O.rms_norm(q, sd[p + "s_attn.norm_q.weight"]), cos, sin)
         k = O.apply_rope(O.rms_norm(k, sd[p + "s_attn.norm_k.weight"]), cos, sin)
         self.q = q
-        r = self.plan.rank if self.is_inflated(i) else 0
+        r = self.plan.frame_rank if self.is_inflated(i) else 0
         self.k[r] = k.reshape(-1)
         self.v[r] = v.reshape(-1)
 
@@ -77,8 +77,8 @@ class OracleEngine:
         shp = (B * T, H, L, hd)
         if self.is_inflated(i):
             # every chunk is (B, T_local, H, L, hd); keys of all chunks are simply concatenated
-            ks = [self.k[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.world)]
-            vs = [self.v[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.world)]
+            ks = [self.k[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.frame_world)]
+            vs = [self.v[c].view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd) for c in range(self.plan.frame_world)]
             q = self.q.view(B, T, H, L, hd).permute(0, 2, 1, 3, 4).reshape(B, H, T * L, hd)
             o = F.scaled_dot_product_attention(q, torch.cat(ks, 2), torch.cat(vs, 2))
             o = o.view(B, H, T, L, hd).permute(0, 2, 3, 1, 4).reshape(B * T, L, C)
@@ -111,7 +111,7 @@ def _inputs():
     return x, ctx, fs, mask, t
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cfg_groups=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -122,15 +122,14 @@ def _worker(rank, world, port, q):
         sd = O.synthetic_state_dict(cfg, seed=0)
         x, ctx, fs, mask, t = _inputs()
         B, T, N, _ = x.shape
-        plan = FrameShardPlan(T, world, rank)
+        plan = FrameShardPlan(T, world, rank, B, cfg_groups)
+        groups = [dist.new_group(plan.frame_group_ranks(g)) for g in range(cfg_groups)] if cfg_groups > 1 else [None]
         cos, sin = rope_tables_host(fs, 128)                         # from the FULL window's framesteps
-        cos = cos.repeat_interleave(2, -1).view(B, T, -1)[:, plan.frame_slice].reshape(-1, 128)
-        sin = sin.repeat_interleave(2, -1).view(B, T, -1)[:, plan.frame_slice].reshape(-1, 128)
-        eng = OracleEngine(sd, cfg, plan, plan.slice_frames(ctx), cos, sin, B, N)
-        t_bt = masked_time(t.tolist(), mask, B, T)
-        tl = plan.frames_local
-        t_local = [t_bt[b * T + rank * tl + j] for b in range(B) for j in range(tl)]
-        v_local = sharded_forward(eng, plan, None, plan.slice_frames(x), t_local)
+        cos = plan.slice_local(cos.repeat_interleave(2, -1).view(B, T, -1)).reshape(-1, 128)
+        sin = plan.slice_local(sin.repeat_interleave(2, -1).view(B, T, -1)).reshape(-1, 128)
+        eng = OracleEngine(sd, cfg, plan, plan.slice_local(ctx), cos, sin, plan.batch_local, N)
+        t_local = plan.local_times(masked_time(t.tolist(), mask, B, T))
+        v_local = sharded_forward(eng, plan, groups[plan.cfg_rank], plan.slice_local(x), t_local)
         v = gather_frames(v_local, plan, None)
         if rank == 0:
             q.put(v)
@@ -138,12 +137,11 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_world2_sharded_forward_equals_unsharded_oracle():
+def _run_world(world, cfg_groups):
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29400 + os.getpid() % 500
-    procs = [ctxm.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29400 + (os.getpid() * 7 + world * 13 + cfg_groups) % 500
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cfg_groups)) for r in range(world)]
     for p in procs:
         p.start()
     v = q.get(timeout=240)
@@ -155,6 +153,18 @@ def test_world2_sharded_forward_equals_unsharded_oracle():
     x, ctx, fs, mask, t = _inputs()
     ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
     assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5), float((v - ref).abs().max())
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,cfg_groups", [(2, 2), (4, 2)])
+def test_cfg_parallel_times_frame_shard_equals_unsharded_oracle(world, cfg_groups):
+    """CFG branches split first (world 2: no K/V exchange at all), then frames (world 4: 2 x 2)."""
+    _run_world(world, cfg_groups)
+
+
+@pytest.mark.timeout(300)
+def test_world2_sharded_forward_equals_unsharded_oracle():
+    _run_world(2, 1)
 
 
 def test_world1_driver_is_identity_plan():

@@ -61,23 +61,35 @@
 
 namespace {
 
-constexpr int QBLK = 256;          // query rows per workgroup
 constexpr int KVBLK = 64;          // keys per sub-tile
 constexpr int HD = 128;
 constexpr int SUB_B = KVBLK * HD * 2;          // one K or V^T sub-tile: 16 KiB
-constexpr int BUF_B = 4 * SUB_B;               // [K0][K1][V0][V1] = 64 KiB per buffer
-constexpr int SMEM_BYTES = 2 * BUF_B;          // 128 KiB
 constexpr int PART_LD = HD + 4;                // floats per partial row: O[128], m, l, pad (16-B aligned rows)
 constexpr int SPLIT_Z = 16;
+// Geometry (template NW = waves per workgroup, NSUB = 64-key sub-tiles per barrier):
+//   NW = 8, NSUB = 2: one 8-wave workgroup per CU, 256 query rows, 128 KiB LDS
+//   NW = 4, NSUB = 1: two independent 4-wave workgroups per CU (128 query rows, 64 KiB LDS each): the two
+//                     waves of a SIMD belong to different workgroups, share no barrier and drift into
+//                     complementary phases (one in softmax while the other issues MFMAs)
+template <int NW, int NSUB>
+struct Geo {
+  static constexpr int QBLK = NW * 32;                 // query rows per workgroup
+  static constexpr int THREADS = NW * 64;
+  static constexpr int UPT = 1024 / THREADS;           // 16-byte DMA units per thread per sub-tile operand
+  static constexpr int BUF_B = 2 * NSUB * SUB_B;       // [K x NSUB][V x NSUB]
+  static constexpr int SMEM = 2 * BUF_B;
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // SPLIT: the workgroup handles only super-tiles [z*ns/Z, (z+1)*ns/Z) (z = blockIdx.z) of query block
 // `qblk_base + blockIdx.x` and writes un-normalised fp32 (O, m, l) partials for attn_combine_kernel.
-template <int DEFER, bool SPLIT>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int tiles_per_chunk, int qblk_base,
-                                                         float* part) {
+template <int DEFER, bool SPLIT, int NW, int NSUB>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, int tiles_per_chunk, int qblk_base,
+                                                             float* part) {
+  using G = Geo<NW, NSUB>;
+  constexpr int QBLK = G::QBLK, UPT = G::UPT, BUF_B = G::BUF_B;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -103,15 +115,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     }
   }
 
-  // ---- DMA descriptors: unit U = j*512 + wave*64 + lane (16 B each) of a 1024-unit sub-tile ----
+  // ---- DMA descriptors: unit U = j*THREADS + wave*64 + lane (16 B each) of a 1024-unit sub-tile ----
   const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;       // per (seq, head), K and V^T alike
-  const bf16_t* k_lane[2];
-  const bf16_t* v_lane[2];
-  int u_byte[2];
+  const bf16_t* k_lane[UPT];
+  const bf16_t* v_lane[UPT];
+  int u_byte[UPT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    u_byte[j] = (j * 512 + wave * 64) * 16;                  // wave-uniform LDS offset of the instruction
-    const int U = j * 512 + wave * 64 + lane;
+  for (int j = 0; j < UPT; ++j) {
+    u_byte[j] = (j * G::THREADS + wave * 64) * 16;           // wave-uniform LDS offset of the instruction
+    const int U = j * G::THREADS + wave * 64 + lane;
     const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
     k_lane[j] = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;
     const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
@@ -119,28 +131,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   }
   // key stream = nchunks x tiles_per_chunk sub-tiles, consumed as super-tiles of up to two
   // sub-tiles that never straddle a chunk
-  const int supers_per_chunk = (tiles_per_chunk + 1) >> 1;
+  const int supers_per_chunk = (tiles_per_chunk + NSUB - 1) / NSUB;
   const int all_supers = p.nchunks * supers_per_chunk;
   const int s_begin = SPLIT ? (int)((int64_t)blockIdx.z * all_supers / gridDim.z) : 0;
   const int s_end = SPLIT ? (int)((int64_t)(blockIdx.z + 1) * all_supers / gridDim.z) : all_supers;
   const int n_supers = s_end - s_begin;
-  int d_tt = (s_begin % supers_per_chunk) * 2;                               // DMA cursor: sub-tile in chunk
+  int d_tt = (s_begin % supers_per_chunk) * NSUB;                            // DMA cursor: sub-tile in chunk
   int64_t d_chunk = (int64_t)(s_begin / supers_per_chunk) * p.chunk_stride;  // element offset of its chunk
   auto dma_sub = [&](unsigned char* kdst, unsigned char* vdst, int tt) __attribute__((always_inline)) {
     const int64_t ko = d_chunk + (int64_t)tt * (KVBLK * HD);
     const int64_t vo = d_chunk + (int64_t)tt * KVBLK;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < UPT; ++j)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(k_lane[j] + ko), (lds_ptr_t)(kdst + u_byte[j]), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < UPT; ++j)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + vo), (lds_ptr_t)(vdst + u_byte[j]), 16, 0, 0);
   };
   auto dma_super = [&](int buf) __attribute__((always_inline)) {     // super-tile at the cursor -> LDS buffer `buf`; advance the cursor
     unsigned char* b = smem + buf * BUF_B;
-    dma_sub(b, b + 2 * SUB_B, d_tt);
-    if (d_tt + 1 < tiles_per_chunk) dma_sub(b + SUB_B, b + 3 * SUB_B, d_tt + 1);
-    d_tt += 2;
+    dma_sub(b, b + NSUB * SUB_B, d_tt);
+    if (NSUB == 2 && d_tt + 1 < tiles_per_chunk) dma_sub(b + SUB_B, b + 3 * SUB_B, d_tt + 1);
+    d_tt += NSUB;
     if (d_tt >= tiles_per_chunk) { d_tt = 0; d_chunk += p.chunk_stride; }
   };
 
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
   for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
-  int c_tt = (s_begin % supers_per_chunk) * 2;   // compute cursor: sub-tile in chunk
+  int c_tt = (s_begin % supers_per_chunk) * NSUB;   // compute cursor: sub-tile in chunk
 
   auto max3 = [](float a, float b, float cc) __attribute__((always_inline)) {
     float d;
@@ -285,9 +297,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
     if (more) dma_super(buf ^ 1);
     const unsigned char* b = smem + buf * BUF_B;
     const int valid = p.sk - c_tt * KVBLK;    // wave-uniform: valid keys from this sub-tile to the chunk end
-    sub_tile(b, b + 2 * SUB_B, valid);
-    if (valid > KVBLK) sub_tile(b + SUB_B, b + 3 * SUB_B, valid - KVBLK);
-    c_tt += 2;
+    sub_tile(b, b + NSUB * SUB_B, valid);
+    if (NSUB == 2 && valid > KVBLK) sub_tile(b + SUB_B, b + 3 * SUB_B, valid - KVBLK);
+    c_tt += NSUB;
     if (c_tt >= tiles_per_chunk) c_tt = 0;
   };
 
@@ -330,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(am_attn_args p, int ti
 
 // merge the Z partials of the split query block: O = sum_z 2^(m_z - m) O_z / sum_z 2^(m_z - m) l_z
 __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const float* __restrict__ part, int Z,
-                                                           int qblk_base, int rows) {
+                                                           int qblk_base, int rows, int QBLK) {
   const int bh = blockIdx.y, row = blockIdx.x;          // one 128-thread block per (sequence*head, row)
   if (row >= rows) return;
   const int d = threadIdx.x;
@@ -348,26 +360,27 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const
   p.O[((int64_t)seq * p.sq + qblk_base * QBLK + row) * p.ldo + head * HD + d] = f2bf(acc / l);
 }
 
-template <int DEFER>
+template <int DEFER, int NW, int NSUB>
 int launch(const am_attn_args* a, void* stream) {
+  using G = Geo<NW, NSUB>;
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, false, NW, NSUB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true, NW, NSUB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     attr_set = true;
   }
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
-  const int all_supers = ((tiles_per_chunk + 1) / 2) * a->nchunks;
-  const int nblk = ceil_div(a->sq, QBLK);
+  const int all_supers = ceil_div(tiles_per_chunk, NSUB) * a->nchunks;
+  const int nblk = ceil_div(a->sq, G::QBLK);
   const int bh = a->nseq * a->heads;
-  const int tail_rows = a->sq - (nblk - 1) * QBLK;
+  const int tail_rows = a->sq - (nblk - 1) * G::QBLK;
   // split the short last query block over the key range when it would otherwise add a round
   static float* part = nullptr;       // library-owned scratch, grown on demand
   static size_t part_elems = 0;
-  const size_t need = (size_t)bh * SPLIT_Z * QBLK * PART_LD;
-  const bool split = nblk >= 9 && tail_rows <= 128 && all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
+  const size_t need = (size_t)bh * SPLIT_Z * G::QBLK * PART_LD;
+  const bool split = nblk >= 9 && tail_rows <= G::QBLK / 2 && all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
   if (split && part_elems < need) {
     if (part) AM_HIP(hipFree(part));
     part = nullptr; part_elems = 0;
@@ -375,12 +388,13 @@ int launch(const am_attn_args* a, void* stream) {
     part_elems = need;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false>), dim3(split ? nblk - 1 : nblk, bh), dim3(512), SMEM_BYTES, st, *a,
-                     tiles_per_chunk, 0, (float*)nullptr);
+  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false, NW, NSUB>), dim3(split ? nblk - 1 : nblk, bh), dim3(G::THREADS), G::SMEM, st,
+                     *a, tiles_per_chunk, 0, (float*)nullptr);
   if (split) {
-    hipLaunchKernelGGL((attn_fwd_kernel<DEFER, true>), dim3(1, bh, SPLIT_Z), dim3(512), SMEM_BYTES, st, *a,
+    hipLaunchKernelGGL((attn_fwd_kernel<DEFER, true, NW, NSUB>), dim3(1, bh, SPLIT_Z), dim3(G::THREADS), G::SMEM, st, *a,
                        tiles_per_chunk, nblk - 1, part);
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(tail_rows, bh), dim3(128), 0, st, *a, part, SPLIT_Z, nblk - 1, tail_rows);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(tail_rows, bh), dim3(128), 0, st, *a, part, SPLIT_Z, nblk - 1, tail_rows,
+                       G::QBLK);
   }
   AM_HIP(hipGetLastError());
   return AM_OK;
@@ -400,8 +414,8 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK(a->Q && a->K && a->Vt && a->O, "am_attention_bf16: null operand");
   AM_CHECK(a->nseq > 0 && a->heads > 0 && a->sq > 0 && a->sk > 0 && a->nchunks > 0,
            "am_attention_bf16: empty problem");
-  AM_CHECK(a->sq_pad % QBLK == 0 && a->sq_pad >= a->sq, "am_attention_bf16: sq_pad=%d must be a multiple of %d and >= sq=%d",
-           a->sq_pad, QBLK, a->sq);
+  AM_CHECK(a->sq_pad % 256 == 0 && a->sq_pad >= a->sq, "am_attention_bf16: sq_pad=%d must be a multiple of 256 and >= sq=%d",
+           a->sq_pad, a->sq);
   AM_CHECK(a->sk_pad % KVBLK == 0 && a->sk_pad >= a->sk, "am_attention_bf16: sk_pad=%d must be a multiple of %d and >= sk=%d",
            a->sk_pad, KVBLK, a->sk);
   AM_CHECK(a->ldo % 4 == 0 && a->ldo >= a->heads * HD, "am_attention_bf16: ldo=%d too small / misaligned", a->ldo);
@@ -412,8 +426,10 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
   switch (a->defer_log2) {
-    case 0: return launch<0>(a, stream);
-    case 8: return launch<8>(a, stream);
+    case 0: return launch<0, 8, 2>(a, stream);
+    case 8: return launch<8, 8, 2>(a, stream);
+    case 50: return launch<0, 4, 1>(a, stream);     // geometry A/B: two 4-wave workgroups per CU
+    case 58: return launch<8, 4, 1>(a, stream);
     default:
 #ifdef AM_ATTN_ABLATIONS
       if (a->defer_log2 >= 100) return am_attention_variant(a, stream);

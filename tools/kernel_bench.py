@@ -45,12 +45,12 @@ def main():
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
         fl = 4.0 * Sq * Sq * C * B
-        for d, nm in ((a.defer, "product"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
+        for d, nm in ((a.defer, "product"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
                       (a.defer + 100, "staggered")):
             if d >= 100 and not a.variants:
                 continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
-            print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:9s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+            print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:12s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         if a.ablate:
             for k, nm in {1: "no exp", 2: "no row max", 3: "no row sum", 4: "no cvt", 5: "V frags not prefetched",
                           6: "no softmax VALU at all"}.items():

@@ -179,3 +179,80 @@ def test_world1_driver_is_identity_plan():
     v = sharded_forward(eng, plan, None, x, masked_time(t.tolist(), mask, B, T))
     ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
     assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# HipDenoiser's own multi-rank plumbing (_plan, _frame_group/new_group, bind_window slicing,
+# forward_host_time, gather) with the HIP engine swapped for the oracle-backed stand-in.
+# ---------------------------------------------------------------------------------------------
+class FakeHipEngine(OracleEngine):
+    """Same constructor / methods as actionmesh_amd.denoiser.HipEngine, computing with the oracle."""
+
+    def __init__(self, hp, state_dict, device, max_batch, frames_local, tokens, ctx_tokens,
+                 world=1, rank=0, attn_defer_log2=8):
+        self.device = torch.device(device)
+        self.world, self.rank = world, rank
+        self.bounds = (max_batch, frames_local, tokens, ctx_tokens)
+        self._cfg = O.OracleConfig(in_channels=hp["in_channels"], num_layers=hp["num_layers"],
+                                   num_attention_heads=hp["num_attention_heads"], width=hp["width"],
+                                   mlp_ratio=hp["mlp_ratio"], cross_attention_dim=hp["cross_attention_dim"],
+                                   inflated_layers=tuple(hp["inflated_layers"]))
+        self._sd = state_dict
+
+    def close(self):
+        pass
+
+    def fits(self, B, T, N, S):
+        b = self.bounds
+        return B <= b[0] and T <= b[1] and N <= b[2] and S <= b[3]
+
+    def set_context(self, ctx_local, cos, sin):
+        B, T, S, _ = ctx_local.shape
+        plan = FrameShardPlan(T * self.world, self.world, self.rank)     # only frame_world/frame_rank are used
+        OracleEngine.__init__(self, self._sd, self._cfg, plan, ctx_local, cos.repeat_interleave(2, -1),
+                              sin.repeat_interleave(2, -1), B, self.bounds[2])
+
+    def forward(self, x_local, t_bt_local):
+        return sharded_forward(self, FrameShardPlan(x_local.shape[1], 1, 0), None, x_local, t_bt_local)
+
+
+def _denoiser_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import actionmesh_amd.denoiser as D
+        torch.set_num_threads(2)
+        D.HipEngine = FakeHipEngine                      # the only substitution
+        cfg = O.OracleConfig(**KW)
+        sd = O.synthetic_state_dict(cfg, seed=0)
+        x, ctx, fs, mask, t = _inputs()
+        model = D.HipDenoiser(num_tokens_nominal=20, temporal_context_size=4, process_group=dist.group.WORLD, **KW)
+        model.load_state_dict(sd)
+        v, cache = model.forward(x, ctx, fs, t, mask, None)
+        v2, cache2 = model.forward(x, ctx, fs, t, mask, cache)
+        assert cache2 is cache and torch.equal(v, v2)
+        if rank == 0:
+            q.put(v)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_hipdenoiser_multirank_plumbing(world):
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29400 + (os.getpid() * 11 + world * 17) % 500
+    procs = [ctxm.Process(target=_denoiser_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    v = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg = O.OracleConfig(**KW)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    x, ctx, fs, mask, t = _inputs()
+    ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
+    assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5), float((v - ref).abs().max())

@@ -340,6 +340,255 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
   }
 }
 
+// ===========================================================================
+// Balanced two-phase schedule.  The two half-workgroups (waves 0-3 / 4-7; wave i and wave i+4 share
+// SIMD i) run exactly one phase apart - waves 4-7 take one extra barrier before the loop, waves 0-3 one
+// after it - and a 64-key tile is cut into two phases of EQUAL weight, separated by barriers:
+//   phase 1: S = K Q'^T (16 MFMA), then the first half of the softmax (row max, rescale, exp of key block 0)
+//   phase 2: second half of the softmax (exp of key block 1, row sums, bf16 P), then O += V^T P^T (16 MFMA)
+// so on every SIMD the wave in phase 1 issues its MFMAs while its partner is in the VALU half of phase 2,
+// and vice versa: MFMA and VALU work of the pair are interleaved by construction instead of colliding
+// (the lockstep loop leaves the matrix pipe idle while both waves are in their softmax).  An earlier
+// staggered variant with unbalanced phases (QK^T | softmax + P.V) did not help: the short phase just waited
+// at the barrier.  Each half-workgroup DMAs its own half of every K / V^T tile; with global phase g = the
+// interval after barrier #g, waves 0-3 run phase 1/2 of tile t at g = 2t / 2t+1, waves 4-7 at 2t+1 / 2t+2:
+//   K(t+1) -> the buffer K(t-1) left at g = 2t-1; issued at the start of phase 1(t), drained before the
+//             issuing half's next barrier, first read at g = 2t+2;
+//   V(t+1) -> the buffer V(t-1) left at g = 2t;   issued at the start of phase 2(t), first read at g = 2t+3.
+// ===========================================================================
+template <int DEFER>
+__global__ __launch_bounds__(512, 2) void attn_fwd_balanced_kernel(am_attn_args p, int tiles_per_chunk) {
+  constexpr int QBLK = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                   // [2][16 KiB]
+  unsigned char* Vs = smem + 2 * SUB_B;       // [2][16 KiB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int head = bh % p.heads, seq = bh / p.heads;
+  const int q0 = blockIdx.x * QBLK + wave * 32;
+  const float c = p.scale * 1.4426950408889634f;
+  const bool late = wave >= 4;
+
+  bf16x8_t qf[8];
+  {
+    const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + l31) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
+      u32x4_t sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf2(bflo(raw[e]) * c, bfhi(raw[e]) * c);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, sc);
+    }
+  }
+  // this half-workgroup's half of every tile: units U = half*512 + j*256 + (wave&3)*64 + lane
+  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+  const bf16_t* k_lane[2];
+  const bf16_t* v_lane[2];
+  int u_byte[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ub = (wave >> 2) * 512 + j * 256 + (wave & 3) * 64;
+    u_byte[j] = ub * 16;
+    const int U = ub + lane;
+    const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+    k_lane[j] = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;
+    const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+    v_lane[j] = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;
+  }
+  const int total_tiles = p.nchunks * tiles_per_chunk;
+  int dk_tt = 0, dv_tt = 0;
+  int64_t dk_chunk = 0, dv_chunk = 0;
+  auto dma_k = [&](int buf) __attribute__((always_inline)) {
+    const int64_t ko = dk_chunk + (int64_t)dk_tt * (KVBLK * HD);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(k_lane[j] + ko), (lds_ptr_t)(Ks + buf * SUB_B + u_byte[j]), 16, 0, 0);
+    if (++dk_tt == tiles_per_chunk) { dk_tt = 0; dk_chunk += p.chunk_stride; }
+  };
+  auto dma_v = [&](int buf) __attribute__((always_inline)) {
+    const int64_t vo = dv_chunk + (int64_t)dv_tt * KVBLK;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(v_lane[j] + vo), (lds_ptr_t)(Vs + buf * SUB_B + u_byte[j]), 16, 0, 0);
+    if (++dv_tt == tiles_per_chunk) { dv_tt = 0; dv_chunk += p.chunk_stride; }
+  };
+
+  f32x16_t o[4], zero16, s[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    zero16[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d][r] = 0.f;
+  }
+  float m_run = 0.f, l_run = 0.f;
+  bool first = true;
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  int c_tt = 0;
+  f32x2_t rsa[4];
+
+  auto max3 = [](float a, float b, float cc) __attribute__((always_inline)) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(cc));
+    return d;
+  };
+  auto exp_block = [&](f32x16_t& sb) __attribute__((always_inline)) {   // P = exp2(S - m_run) for one key block
+    const f32x2_t m2 = {m_run, m_run};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2_t x = f32x2_t{sb[r], sb[r + 1]} - m2;
+      const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+      sb[r] = pp[0];
+      sb[r + 1] = pp[1];
+      rsa[(r >> 1) & 3] += pp;
+    }
+  };
+
+  auto phase1 = [&](int buf, bool more) __attribute__((always_inline)) {
+    dma_drain_barrier();
+    if (more) dma_k(buf ^ 1);
+    const unsigned char* kp = Ks + buf * SUB_B;
+    {
+      bf16x8_t kf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + k_off[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0], 0, 0, 0);
+        kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * 256 + k_off[ks]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1], 0, 0, 0);
+    }
+    // ---- softmax, first half: row max, rescale, exp of key block 0 ------------------------------
+    asm volatile("s_nop 15" : "+v"(s[0]), "+v"(s[1]));     // MFMA result -> inline-asm VALU read hazard
+    float mxa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(s[0][i], s[1][i], s[0][i + 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 4], s[0][i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 8], s[0][i + 12]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 12], mxa[i]);
+    float mx = max3(mxa[0], mxa[1], max3(mxa[2], mxa[3], mxa[3]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+    }
+    mx -= m_run;
+    if (first || !__all(mx <= (float)DEFER)) {
+      const float delta = first ? mx : fmaxf(mx, 0.f);
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      first = false;
+      m_run += delta;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsa[i] = f32x2_t{0.f, 0.f};
+    exp_block(s[0]);
+  };
+
+  auto phase2 = [&](int buf, bool more) __attribute__((always_inline)) {
+    dma_drain_barrier();
+    if (more) dma_v(buf ^ 1);
+    const unsigned char* vp = Vs + buf * SUB_B;
+    bf16x8_t vf[8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
+    // ---- softmax, second half: exp of key block 1, row sums, bf16 P ---------------------------------
+    exp_block(s[1]);
+    {
+      const f32x2_t rs = (rsa[0] + rsa[1]) + (rsa[2] + rsa[3]);
+      l_run += rs[0] + rs[1];
+    }
+    const int valid = p.sk - c_tt * KVBLK;
+    if (++c_tt == tiles_per_chunk) c_tt = 0;
+    if (valid < KVBLK) {
+      int cnt = 0;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cnt += min(4, max(0, kb * 32 + 8 * g + 4 * hi + 4 - valid));
+      l_run -= (float)cnt * __builtin_amdgcn_exp2f(-m_run);
+    }
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+      pf[kk] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
+        vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 2; kk < 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(kk - 2) * 4 + d], pf[kk], o[d], 0, 0, 0);
+  };
+
+  dma_k(0);
+  dma_v(0);
+  if (late) dma_drain_barrier();                 // waves 4-7 start one phase late
+  for (int t = 0; t < total_tiles; t += 2) {
+    phase1(0, t + 1 < total_tiles);
+    phase2(0, t + 1 < total_tiles);
+    if (t + 1 < total_tiles) {
+      phase1(1, t + 2 < total_tiles);
+      phase2(1, t + 2 < total_tiles);
+    }
+  }
+  if (!late) __syncthreads();                    // balance the barrier count
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.sq) {
+    bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
+      }
+  }
+}
+
 // merge the Z partials of the split query block: O = sum_z 2^(m_z - m) O_z / sum_z 2^(m_z - m) l_z
 __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const float* __restrict__ part, int Z,
                                                            int qblk_base, int rows, int QBLK) {
@@ -360,11 +609,14 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const
   p.O[((int64_t)seq * p.sq + qblk_base * QBLK + row) * p.ldo + head * HD + d] = f2bf(acc / l);
 }
 
-template <int DEFER, int NW, int NSUB>
+template <int DEFER, int NW, int NSUB, bool BALANCED = false>
 int launch(const am_attn_args* a, void* stream) {
   using G = Geo<NW, NSUB>;
   static bool attr_set = false;
   if (!attr_set) {
+    if (BALANCED)
+      AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_balanced_kernel<DEFER>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUB_B));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, false, NW, NSUB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true, NW, NSUB>),
@@ -388,8 +640,12 @@ int launch(const am_attn_args* a, void* stream) {
     part_elems = need;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false, NW, NSUB>), dim3(split ? nblk - 1 : nblk, bh), dim3(G::THREADS), G::SMEM, st,
-                     *a, tiles_per_chunk, 0, (float*)nullptr);
+  if (BALANCED)
+    hipLaunchKernelGGL((attn_fwd_balanced_kernel<DEFER>), dim3(split ? nblk - 1 : nblk, bh), dim3(512), 4 * SUB_B, st, *a,
+                       tiles_per_chunk);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false, NW, NSUB>), dim3(split ? nblk - 1 : nblk, bh), dim3(G::THREADS), G::SMEM,
+                       st, *a, tiles_per_chunk, 0, (float*)nullptr);
   if (split) {
     hipLaunchKernelGGL((attn_fwd_kernel<DEFER, true, NW, NSUB>), dim3(1, bh, SPLIT_Z), dim3(G::THREADS), G::SMEM, st, *a,
                        tiles_per_chunk, nblk - 1, part);
@@ -430,6 +686,8 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
     case 8: return launch<8, 8, 2>(a, stream);
     case 50: return launch<0, 4, 1>(a, stream);     // geometry A/B: two 4-wave workgroups per CU
     case 58: return launch<8, 4, 1>(a, stream);
+    case 70: return launch<0, 8, 2, true>(a, stream);   // balanced two-phase schedule
+    case 78: return launch<8, 8, 2, true>(a, stream);
     default:
 #ifdef AM_ATTN_ABLATIONS
       if (a->defer_log2 >= 100) return am_attention_variant(a, stream);

@@ -240,7 +240,7 @@ def _sdpa_ref(q, k, v):
                                                   (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1),
                                                   # short last query block -> split-KV tail path (+ chunks)
                                                   (1, 2, 2320, 4200, 1), (2, 1, 2305, 4224, 2), (1, 1, 2432, 4097, 1)])
-@pytest.mark.parametrize("defer", [0, 8, 58])    # 58 = threshold 8 with the 2 x 4-wave workgroup geometry
+@pytest.mark.parametrize("defer", [0, 8, 58, 78])  # 58: 2 x 4-wave workgroup geometry, 78: balanced two-phase schedule
 def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     from actionmesh_amd import ops
     q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)

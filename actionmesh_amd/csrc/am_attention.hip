@@ -609,8 +609,15 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const
   p.O[((int64_t)seq * p.sq + qblk_base * QBLK + row) * p.ldo + head * HD + d] = f2bf(acc / l);
 }
 
-template <int DEFER, int NW, int NSUB, bool BALANCED = false>
+}  // namespace
+int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream);  // am_attention64.hip
+namespace {
+
+// MAIN: 0 = this file's 8-wave kernel, 1 = balanced two-phase variant, 2 = the 4x64 kernel of am_attention64.hip
+// (the split tail and odd shapes always run the 8-wave kernel: same 256-row query blocks)
+template <int DEFER, int NW, int NSUB, int MAIN = 0>
 int launch(const am_attn_args* a, void* stream) {
+  constexpr bool BALANCED = MAIN == 1;
   using G = Geo<NW, NSUB>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -640,7 +647,9 @@ int launch(const am_attn_args* a, void* stream) {
     part_elems = need;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (BALANCED)
+  if (MAIN == 2)
+    AM_TRY(am_attention64_main(a, tiles_per_chunk, split ? nblk - 1 : nblk, DEFER, stream));
+  else if (BALANCED)
     hipLaunchKernelGGL((attn_fwd_balanced_kernel<DEFER>), dim3(split ? nblk - 1 : nblk, bh), dim3(512), 4 * SUB_B, st, *a,
                        tiles_per_chunk);
   else
@@ -686,8 +695,10 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
     case 8: return launch<8, 8, 2>(a, stream);
     case 50: return launch<0, 4, 1>(a, stream);     // geometry A/B: two 4-wave workgroups per CU
     case 58: return launch<8, 4, 1>(a, stream);
-    case 70: return launch<0, 8, 2, true>(a, stream);   // balanced two-phase schedule
-    case 78: return launch<8, 8, 2, true>(a, stream);
+    case 60: return launch<0, 8, 2, 2>(a, stream);   // 4 waves x 64 rows, one wave per SIMD (am_attention64.hip)
+    case 68: return launch<8, 8, 2, 2>(a, stream);
+    case 70: return launch<0, 8, 2, 1>(a, stream);   // balanced two-phase schedule
+    case 78: return launch<8, 8, 2, 1>(a, stream);
     default:
 #ifdef AM_ATTN_ABLATIONS
       if (a->defer_log2 >= 100) return am_attention_variant(a, stream);

@@ -1,0 +1,411 @@
+// Flash attention forward, "4 x 64" structure: one workgroup = 4 waves = ONE wave per SIMD, each wave owns
+// 64 query rows (two 32-row blocks j = 0, 1) and the whole 512-register file.  Same maths, operand layouts
+// and LDS images as am_attention.hip (read its header first); what changes is the work per wave:
+//   * every K / V^T fragment read from LDS feeds TWO MFMAs (one per query block): half the LDS reads,
+//     DMA instructions and barriers per MFMA of the 8-wave kernel;
+//   * the softmax of tile g runs in the issue gaps of the MFMAs of its neighbours, inside one wave, so
+//     the overlap does not depend on how the SIMD arbitrates between two waves:
+//         phase 1(g):  O += V^T(g-1) P^T(g-1)   (32 MFMA)  ||  softmax of block 0 of tile g
+//         phase 2(g):  S(g+1) = K(g+1) Q^T      (32 MFMA)  ||  softmax of block 1 of tile g
+//     each phase = [8 MFMA || row max] -> rare rescale branch -> [24 MFMA || exp, row sum, bf16 pack];
+//   * the running max is folded into the MFMA: the score accumulators start at -m_run (a 16-register
+//     splat per block, rewritten only when a row's max grows past the deferred-rescale threshold), so
+//     scores are born as S - m_run and the per-element subtraction disappears.  Block 1's accumulators
+//     are initialised while its previous softmax may still move m_run; that offset is carried as a
+//     pending correction (`pend`), applied in the (rare) tile after a rescale;
+//   * K/V^T tiles (64 keys) live in a 4-deep LDS ring (128 KiB): in iteration g the MFMAs read V^T(g-1) and
+//     K(g+1), tile g+2 is in flight (LDS-DMA), one barrier per tile;
+//   * the padded keys of a chunk's partial last tile score exactly 0 and their exp2(-m) is removed from the
+//     row sums once, after the loop (rescales multiply it like every other term).
+// Compiled with -fno-slp-vectorize (v_pk_*_f32 beside MFMAs costs more than two scalar ops on gfx950) and
+// IEEE mode off for this file, so fmaxf chains become v_max3_f32 without canonicalising v_max's and hipcc
+// (not hand-written asm) owns every MFMA -> VALU hazard.
+#include "am_common.h"
+
+namespace {
+
+constexpr int KVBLK = 64;
+constexpr int HD = 128;
+constexpr int SUB_B = KVBLK * HD * 2;       // one K or V^T tile: 16 KiB
+constexpr int STAGE_B = 2 * SUB_B;          // [K tile][V^T tile]
+constexpr int NSTAGE = 4;
+constexpr int QBLK = 256;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#include "am_attention64_asm.inc"
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+// Pins a value to this point of the instruction stream: the (empty) volatile asm is ordered with the MFMA asm
+// statements, so the producer of x cannot be sunk or hoisted to another phase by the optimiser.
+#define PIN(x) asm volatile("" : "+v"(x))
+
+// ---- softmax of one 32-query block, cut into single-instruction steps that the phases thread through their
+//      MFMA gaps.  sa/sb = the block's scores for keys 0-31 / 32-63 of the tile (already relative to m_run). ----
+struct RowMax {            // 20 steps: four v_max3 chains, cross-half swap
+  float a[4];
+  float mx;
+  __device__ __forceinline__ void step(int n, const f32x16_t& sa, const f32x16_t& sb) {
+    if (n < 4) { a[n] = max3(sa[n], sb[n], sa[n + 4]); PIN(a[n]); }
+    else if (n < 8) { a[n - 4] = max3(a[n - 4], sb[n], sa[n + 4]); PIN(a[n - 4]); }
+    else if (n < 12) { a[n - 8] = max3(a[n - 8], sb[n], sa[n + 4]); PIN(a[n - 8]); }
+    else if (n < 16) { a[n - 12] = __builtin_fmaxf(a[n - 12], sb[n]); PIN(a[n - 12]); }
+    else if (n == 16) { a[2] = __builtin_fmaxf(a[2], a[3]); PIN(a[2]); }
+    else if (n == 17) { mx = max3(a[0], a[1], a[2]); PIN(mx); }
+    else if (n == 18) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      a[0] = __uint_as_float(sw[0]);
+      a[1] = __uint_as_float(sw[1]);
+      PIN(a[0]);
+    } else { mx = __builtin_fmaxf(a[0], a[1]); PIN(mx); }
+  }
+};
+struct ExpSumPack {        // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, skewed by one pair
+  float rs[4];
+  __device__ __forceinline__ void init() { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; }
+  __device__ __forceinline__ static float get(const f32x16_t& sa, const f32x16_t& sb, int e) { return e < 16 ? sa[e] : sb[e - 16]; }
+  __device__ __forceinline__ void ex(f32x16_t& sa, f32x16_t& sb, int e) {
+    float v = __builtin_amdgcn_exp2f(get(sa, sb, e));
+    PIN(v);
+    if (e < 16) sa[e] = v;
+    else sb[e - 16] = v;
+  }
+  __device__ __forceinline__ void ad(f32x16_t& sa, f32x16_t& sb, int e) { rs[e & 3] += get(sa, sb, e); PIN(rs[e & 3]); }
+  __device__ __forceinline__ void pk(f32x16_t& sa, f32x16_t& sb, int pr, u32x4_t (&w)[4]) {
+    uint32_t v = pack_bf2(get(sa, sb, 2 * pr), get(sa, sb, 2 * pr + 1));
+    PIN(v);
+    w[pr >> 2][pr & 3] = v;
+  }
+  __device__ __forceinline__ void step(int n, f32x16_t& sa, f32x16_t& sb, u32x4_t (&w)[4]) {
+    if (n < 2) { ex(sa, sb, n); return; }
+    if (n >= 77) {
+      if (n == 77) ad(sa, sb, 30);
+      else if (n == 78) ad(sa, sb, 31);
+      else pk(sa, sb, 15, w);
+      return;
+    }
+    const int r = (n - 2) / 5 + 1, k = (n - 2) % 5;     // round r = 1..15
+    if (k == 0) ex(sa, sb, 2 * r);
+    else if (k == 1) ex(sa, sb, 2 * r + 1);
+    else if (k == 2) ad(sa, sb, 2 * r - 2);
+    else if (k == 3) ad(sa, sb, 2 * r - 1);
+    else pk(sa, sb, r - 1, w);
+  }
+  __device__ __forceinline__ float total() const { return (rs[0] + rs[1]) + (rs[2] + rs[3]); }
+};
+
+template <int DEFER>
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = __builtin_amdgcn_workitem_id_x();
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = __builtin_amdgcn_workgroup_id_y();
+  const int head = bh % p.heads, seq = bh / p.heads;
+  const int q0 = __builtin_amdgcn_workgroup_id_x() * QBLK + wave * 64;
+  const float c = p.scale * 1.4426950408889634f;
+
+  // ---- Q fragments (B operand) of both query blocks, pre-scaled to log2 units, parked in a[128:191] ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + 32 * j + l31) * HD + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q_write((j * 8 + ks) * 4 + e, pack_bf2(bflo(raw[e]) * c, bfhi(raw[e]) * c));
+    }
+  }
+  o_zero();
+
+  // ---- LDS-DMA: 16-byte unit U = i*256 + wave*64 + lane of a 1024-unit tile operand, i = 0..3 ----
+  const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+  const int x = wave * 64 + lane;
+  const int kr = x >> 4, kc = (x & 15) ^ (kr & 15);
+  const bf16_t* k_lane = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;                    // + i * 16 rows
+  const int vr = x >> 3, vc = (x & 7) ^ ((vr >> 1) & 7);
+  const bf16_t* v_lane = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;   // + i * 32 rows
+  const int64_t v_step = (int64_t)32 * p.sk_pad;
+  const int n_tiles = p.nchunks * tiles_per_chunk;
+  int d_tt = 0;
+  int64_t d_chunk = 0;
+  auto dma_tile = [&](int stage) __attribute__((always_inline)) {
+    unsigned char* kdst = smem + stage * STAGE_B + wave * 1024;
+    const bf16_t* ks = k_lane + d_chunk + (int64_t)d_tt * (KVBLK * HD);
+    const bf16_t* vs = v_lane + d_chunk + (int64_t)d_tt * KVBLK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + i * 16 * HD), (lds_ptr_t)(kdst + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + i * v_step), (lds_ptr_t)(kdst + SUB_B + i * 4096), 16, 0, 0);
+    if (++d_tt == tiles_per_chunk) { d_tt = 0; d_chunk += p.chunk_stride; }
+  };
+
+  // fragment read offsets (bytes) inside a ring stage
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = SUB_B + l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  auto k_frag = [&](const unsigned char* st, int kb, int ks) __attribute__((always_inline)) {
+    return *reinterpret_cast<const bf16x8_t*>(st + kb * 32 * 256 + k_off[ks]);
+  };
+  auto v_frag = [&](const unsigned char* st, int d, int kk) __attribute__((always_inline)) {
+    return *reinterpret_cast<const bf16x8_t*>(st + d * 32 * 128 + v_off[kk]);
+  };
+
+  // ---- state (arch VGPRs) ----
+  f32x16_t s0[2];            // block 0: S(g) on entry of an iteration, S(g+1) on exit (same registers)
+  f32x16_t s1[2][2];         // block 1: ping-pong sets, S(g) in s1[cur], S(g+1) born in s1[cur^1]
+  u32x4_t p0[2][4];          // block 0 P (bf16 pairs): P(g-1) in p0[cur], P(g) born in p0[cur^1]
+  u32x4_t p1[4];             // block 1 P: P(g-1) consumed in phase 1, P(g) born in phase 2 (same registers)
+  f32x16_t negm[2];          // -m_run splat: C operand of the first k-step
+  bf16x8_t vq[4];            // V^T fragments of the next P.V step (prefetched across the barrier)
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  float off1 = 0.f;
+  bool pend1 = false;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[0][r] = negm[1][r] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) p0[0][kk] = p0[1][kk] = p1[kk] = u32x4_t{0u, 0u, 0u, 0u};
+  // Opaque to the optimiser: these are real, loop-carried registers from here on.  (As known constants, the
+  // C operand of a first-k-step MFMA was a dying temporary that hipcc re-used for a ds_read straight after the
+  // asm statement - an MFMA reads SrcC over its passes, and hipcc pads SrcC write-after-read only for MFMAs
+  // it knows about.)
+  PIN(negm[0]); PIN(negm[1]);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { PIN(p0[0][kk]); PIN(p0[1][kk]); PIN(p1[kk]); }
+
+  // ---- prologue: tiles 0 and 1 in flight; V^T of ring stage 3 zeroed (iteration 0 multiplies it by P = 0) ----
+  dma_tile(0);
+  if (n_tiles > 1) dma_tile(1);
+  {
+    unsigned char* z = smem + 3 * STAGE_B + SUB_B + tid * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(z + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  }
+  dma_drain_barrier();
+  auto first_scores = [&](f32x16_t (&s1c)[2]) __attribute__((always_inline)) {   // S(0) = K(0) Q^T
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8_t kf = k_frag(smem, kb, ks);
+        if (ks == 0) { s0[kb] = qk_mfma_first(ks, kf, negm[0]); s1c[kb] = qk_mfma_first(8 + ks, kf, negm[1]); }
+        else { qk_mfma_acc(ks, kf, s0[kb]); qk_mfma_acc(8 + ks, kf, s1c[kb]); }
+      }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) vq[d] = v_frag(smem + 3 * STAGE_B, d, 0);
+    asm volatile("" :: "v"(negm[0]), "v"(negm[1]));     // SrcC of the first k-step stays allocated until here
+  };
+
+  // ---- one tile.  cur = ping-pong set holding S(g) of block 1 and P(g-1) of block 0 ----
+  auto iteration = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
+                       u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
+    dma_drain_barrier();                       // tile g+1 landed; every wave is done with ring stage (g+2)&3
+    if (g + 2 < n_tiles) dma_tile((g + 2) & 3);
+    const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
+    const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
+    const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
+    const bool first = g == 0;
+    bf16x8_t vn[4], kq[2][2];
+    RowMax rm;
+    ExpSumPack es;
+
+    // ===== phase 1a: first 8 P.V MFMAs || row max of block 0 =====
+    FENCE();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      pv_mfma(d, vq[d], __builtin_bit_cast(bf16x8_t, p0c[0]));
+      vn[d] = v_frag(v_st, d, 1);
+#pragma unroll
+      for (int n = (20 * (2 * d) + 7) / 8; n < (20 * (2 * d + 1) + 7) / 8; ++n) rm.step(n, s0[0], s0[1]);
+      FENCE();
+      pv_mfma(4 + d, vq[d], __builtin_bit_cast(bf16x8_t, p1[0]));
+#pragma unroll
+      for (int n = (20 * (2 * d + 1) + 7) / 8; n < (20 * (2 * d + 2) + 7) / 8; ++n) rm.step(n, s0[0], s0[1]);
+      FENCE();
+    }
+    bool flag0 = false;
+    float alpha0 = 1.f;
+    if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 0, re-base its scores
+      const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
+      alpha0 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      m_run[0] += delta;
+      l_run[0] *= alpha0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[0][r] -= delta; s0[1][r] -= delta; negm[0][r] = -m_run[0]; }
+      flag0 = true;
+    }
+    // ===== phase 1b: 24 P.V MFMAs || exp / row sum / bf16 pack of block 0; K(g+1) prefetch =====
+    es.init();
+    FENCE();
+#pragma unroll
+    for (int kk = 1; kk < 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int gap = ((kk - 1) * 4 + d) * 2;
+        vq[d] = vn[d];
+        pv_mfma(d, vq[d], __builtin_bit_cast(bf16x8_t, p0c[kk]));
+        if (kk < 3) vn[d] = v_frag(v_st, d, kk + 1);
+        else kq[d >> 1][d & 1] = k_frag(k_st, d & 1, d >> 1);
+#pragma unroll
+        for (int n = (80 * gap + 23) / 24; n < (80 * (gap + 1) + 23) / 24; ++n) es.step(n, s0[0], s0[1], p0n);
+        FENCE();
+        pv_mfma(4 + d, vq[d], __builtin_bit_cast(bf16x8_t, p1[kk]));
+#pragma unroll
+        for (int n = (80 * (gap + 1) + 23) / 24; n < (80 * (gap + 2) + 23) / 24; ++n) es.step(n, s0[0], s0[1], p0n);
+        FENCE();
+      }
+    }
+    l_run[0] += es.total();
+    if (flag0) o_scale(0, alpha0);             // rare: O of block 0 is complete through tile g-1 only now
+    if (pend1) {                               // rare: S(g) of block 1 was born before block 1's last re-base
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1c[0][r] -= off1; s1c[1][r] -= off1; }
+      pend1 = false;
+    }
+
+    // ===== phase 2a: first 8 QK^T MFMAs || row max of block 1 =====
+    FENCE();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int gap = (ks * 2 + kb) * 2;
+        const bf16x8_t kf = kq[ks][kb];
+        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf, negm[0]);
+        else qk_mfma_acc(ks, kf, s0[kb]);
+#pragma unroll
+        for (int n = (20 * gap + 7) / 8; n < (20 * (gap + 1) + 7) / 8; ++n) rm.step(n, s1c[0], s1c[1]);
+        FENCE();
+        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf, negm[1]);
+        else qk_mfma_acc(8 + ks, kf, s1n[kb]);
+        kq[ks][kb] = k_frag(k_st, kb, ks + 2);
+#pragma unroll
+        for (int n = (20 * (gap + 1) + 7) / 8; n < (20 * (gap + 2) + 7) / 8; ++n) rm.step(n, s1c[0], s1c[1]);
+        FENCE();
+      }
+    }
+    if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 1
+      const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
+      const float a1 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      m_run[1] += delta;
+      l_run[1] *= a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1c[0][r] -= delta; s1c[1][r] -= delta; negm[1][r] = -m_run[1]; }
+      off1 = delta;                            // S(g+1) of block 1 is already accumulating on the old -m_run
+      pend1 = true;
+      o_scale(1, a1);
+    }
+    // ===== phase 2b: 24 QK^T MFMAs || exp / row sum / bf16 pack of block 1; V^T(g) prefetch =====
+    es.init();
+    FENCE();
+#pragma unroll
+    for (int ks = 2; ks < 8; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int gap = ((ks - 2) * 2 + kb) * 2;
+        const bf16x8_t kf = kq[ks & 1][kb];
+        qk_mfma_acc(ks, kf, s0[kb]);
+#pragma unroll
+        for (int n = (80 * gap + 23) / 24; n < (80 * (gap + 1) + 23) / 24; ++n) es.step(n, s1c[0], s1c[1], p1);
+        FENCE();
+        qk_mfma_acc(8 + ks, kf, s1n[kb]);
+        if (ks < 6) kq[ks & 1][kb] = k_frag(k_st, kb, ks + 2);
+        else vq[(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
+#pragma unroll
+        for (int n = (80 * (gap + 1) + 23) / 24; n < (80 * (gap + 2) + 23) / 24; ++n) es.step(n, s1c[0], s1c[1], p1);
+        FENCE();
+      }
+    }
+    l_run[1] += es.total();
+  };
+
+  // ---- main loop, two tiles per trip so the ping-pong sets are compile-time names ----
+  int g = 0;
+  if (n_tiles & 1) {
+    first_scores(s1[1]);
+    iteration(0, s1[1], s1[0], p0[1], p0[0]);
+    g = 1;
+  } else {
+    first_scores(s1[0]);
+  }
+  for (; g < n_tiles; g += 2) {
+    iteration(g, s1[0], s1[1], p0[0], p0[1]);
+    iteration(g + 1, s1[1], s1[0], p0[1], p0[0]);
+  }
+
+  // The last iteration's QK^T MFMAs (scores of a tile that does not exist) are still in flight and hipcc does
+  // not know they are MFMAs: hold their destination registers until the results have landed, or the epilogue's
+  // temporaries allocated there are overwritten (MFMA D -> any writer: 12 wait states).
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0][0]), "+v"(s1[0][1]), "+v"(s1[1][0]), "+v"(s1[1][1]));
+
+  // ---- drain: O += V^T(n-1) P^T(n-1)  (P of block 0 is in p0[0] after an odd-set iteration) ----
+  {
+    const unsigned char* v_st = smem + ((n_tiles + 3) & 3) * STAGE_B;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8_t vfr = kk == 0 ? vq[d] : v_frag(v_st, d, kk);
+        pv_mfma(d, vfr, __builtin_bit_cast(bf16x8_t, p0[0][kk]));
+        pv_mfma(4 + d, vfr, __builtin_bit_cast(bf16x8_t, p1[kk]));
+      }
+  }
+  o_read_fence();
+
+  // ---- epilogue: remove the padded keys' exp2(0 - m) (one partial tile per chunk), normalise, store ----
+  const int pad_valid = p.sk - (tiles_per_chunk - 1) * KVBLK;      // valid keys in a chunk's last tile
+  int cnt = 0;
+  if (pad_valid < KVBLK) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) cnt += min(4, max(0, kb * 32 + 8 * gq + 4 * hi + 4 - pad_valid));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float l = l_run[j] - (float)(cnt * p.nchunks) * __builtin_amdgcn_exp2f(-m_run[j]);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = q0 + 32 * j + l31;
+    if (q < p.sq) {
+      bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4_t ov = o_read4(j * 4 + d, gq);
+          u32x2_t w;
+          w[0] = pack_bf2(ov[0] * inv, ov[1] * inv);
+          w[1] = pack_bf2(ov[2] * inv, ov[3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * gq) = w;
+        }
+    }
+  }
+}
+
+}  // namespace
+
+// Main (non-split) grid of the 4x64 kernel: query blocks [0, nblk_main) of every (sequence, head).
+int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
+    attr_set = true;
+  }
+  const dim3 grid(nblk_main, a->nseq * a->heads);
+  if (defer == 0)
+    hipLaunchKernelGGL((attn_fwd64_kernel<0>), grid, dim3(256), NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk);
+  else
+    hipLaunchKernelGGL((attn_fwd64_kernel<8>), grid, dim3(256), NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk);
+  return AM_OK;
+}

@@ -240,7 +240,7 @@ def _sdpa_ref(q, k, v):
                                                   (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1),
                                                   # short last query block -> split-KV tail path (+ chunks)
                                                   (1, 2, 2320, 4200, 1), (2, 1, 2305, 4224, 2), (1, 1, 2432, 4097, 1)])
-@pytest.mark.parametrize("defer", [0, 8, 58, 78])  # 58: 2 x 4-wave workgroup geometry, 78: balanced two-phase schedule
+@pytest.mark.parametrize("defer", [0, 8, 58, 78, 60, 68])  # 58: 2 x 4-wave geometry, 78: balanced two-phase, 60/68: 4 waves x 64 rows
 def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     from actionmesh_amd import ops
     q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)

@@ -613,11 +613,14 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const
 int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream);  // am_attention64.hip
 namespace {
 
-// MAIN: 0 = this file's 8-wave kernel, 1 = balanced two-phase variant, 2 = the 4x64 kernel of am_attention64.hip
-// (the split tail and odd shapes always run the 8-wave kernel: same 256-row query blocks)
+// MAIN: 0 = this file's 8-wave kernel, 1 = balanced two-phase variant, 2 = the 4x64 kernel of am_attention64.hip,
+// 3 = product dispatch: 4x64 for long key streams (>= 16 tiles: its pipeline needs a few tiles to fill and its
+// per-workgroup prologue is heavier - cross-attention with 257 keys runs 15 % faster on the 8-wave kernel).
+// The split tail always runs the 8-wave kernel (same 256-row query blocks).
 template <int DEFER, int NW, int NSUB, int MAIN = 0>
 int launch(const am_attn_args* a, void* stream) {
   constexpr bool BALANCED = MAIN == 1;
+  const bool use64 = MAIN == 2 || (MAIN == 3 && ceil_div(a->sk, KVBLK) * a->nchunks >= 16);
   using G = Geo<NW, NSUB>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -647,7 +650,7 @@ int launch(const am_attn_args* a, void* stream) {
     part_elems = need;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (MAIN == 2)
+  if (use64)
     AM_TRY(am_attention64_main(a, tiles_per_chunk, split ? nblk - 1 : nblk, DEFER, stream));
   else if (BALANCED)
     hipLaunchKernelGGL((attn_fwd_balanced_kernel<DEFER>), dim3(split ? nblk - 1 : nblk, bh), dim3(512), 4 * SUB_B, st, *a,
@@ -672,6 +675,8 @@ int am_attention_variant(const am_attn_args* a, void* stream);   // am_attention
 #endif
 
 // defer_log2: 0 or 8 = deferred-rescale threshold in log2 units (0 = rescale whenever a max grows).
+// Other codes force one kernel for A/B runs and parity tests: +60 the 4x64 kernel, +90 the 8-wave kernel,
+// +50 / +70 its geometry / schedule variants.
 // Builds with -DAM_ATTN_ABLATIONS also accept the experimental schedules of am_attention_variants.hip
 // (defer_log2 >= 100, used by tools/kernel_bench.py for A/B measurements).
 extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
@@ -691,8 +696,10 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
   switch (a->defer_log2) {
-    case 0: return launch<0, 8, 2>(a, stream);
-    case 8: return launch<8, 8, 2>(a, stream);
+    case 0: return launch<0, 8, 2, 3>(a, stream);
+    case 8: return launch<8, 8, 2, 3>(a, stream);
+    case 90: return launch<0, 8, 2>(a, stream);      // forced 8-wave kernel (A/B, tests)
+    case 98: return launch<8, 8, 2>(a, stream);
     case 50: return launch<0, 4, 1>(a, stream);     // geometry A/B: two 4-wave workgroups per CU
     case 58: return launch<8, 4, 1>(a, stream);
     case 60: return launch<0, 8, 2, 2>(a, stream);   // 4 waves x 64 rows, one wave per SIMD (am_attention64.hip)
@@ -701,6 +708,7 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
     case 78: return launch<8, 8, 2, 1>(a, stream);
     default:
 #ifdef AM_ATTN_ABLATIONS
+      if (a->defer_log2 >= 3000) return launch<8, 8, 2, 2>(a, stream);     // 4x64 timing ablations
       if (a->defer_log2 >= 100) return am_attention_variant(a, stream);
 #endif
       AM_FAIL(AM_ERR_INVALID, "am_attention_bf16: defer_log2 must be 0 or 8 (got %d)", a->defer_log2);

@@ -41,6 +41,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 // Pins a value to this point of the instruction stream: the (empty) volatile asm is ordered with the MFMA asm
 // statements, so the producer of x cannot be sunk or hoisted to another phase by the optimiser.
 #define PIN(x) asm volatile("" : "+v"(x))
+// Keeps MFMA source registers allocated up to this point.  hipcc treats an MFMA asm statement like any other
+// instruction and hands its A/B registers to the next ds_read / VALU result as soon as the statement has issued;
+// the hardware then holds that writer until the (queued) MFMA has fetched its operands - measured at ~28 cycles
+// per LDS fragment read, 7 ms of a 29 ms kernel.
+#define HOLD2(a, b) asm volatile("" :: "v"(a), "v"(b))
+#define HOLD4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
 
 // ---- softmax of one 32-query block, cut into single-instruction steps that the phases thread through their
 //      MFMA gaps.  sa/sb = the block's scores for keys 0-31 / 32-63 of the tile (already relative to m_run). ----
@@ -62,12 +68,30 @@ struct RowMax {            // 20 steps: four v_max3 chains, cross-half swap
     } else { mx = __builtin_fmaxf(a[0], a[1]); PIN(mx); }
   }
 };
-struct ExpSumPack {        // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, skewed by one pair
+// Issue-slot cost model for spreading the 80 exp/sum/pack steps over a phase's 24 MFMA gaps: a wave issues one
+// instruction per 4 cycles and v_exp_f32 holds the port for two slots (tools/ubench/mfma_fillers.hip), so a
+// step costs 2 (exp) or 1; gap i of 24 takes the steps whose cumulative cost starts in [112 i / 24, 112 (i+1) / 24).
+__device__ __host__ constexpr bool es_is_exp(int n) { return n < 2 || (n < 77 && (n - 2) % 5 < 2); }
+__device__ __host__ constexpr int es_cost_before(int n) { int c = 0; for (int i = 0; i < n; ++i) c += es_is_exp(i) ? 2 : 1; return c; }
+__device__ __host__ constexpr int es_gap_of(int n) { return es_cost_before(n) * 24 / 112; }
+struct EsTab { int lo[25]; };        // steps [lo[i], lo[i+1]) go into gap i
+__device__ __host__ constexpr EsTab es_make_tab() {
+  EsTab t{};
+  for (int i = 0; i <= 24; ++i) {
+    int n = 0;
+    while (n < 80 && es_gap_of(n) < i) ++n;
+    t.lo[i] = n;
+  }
+  return t;
+}
+
+template <int ABL>
+struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, skewed by one pair
   float rs[4];
   __device__ __forceinline__ void init() { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; }
   __device__ __forceinline__ static float get(const f32x16_t& sa, const f32x16_t& sb, int e) { return e < 16 ? sa[e] : sb[e - 16]; }
   __device__ __forceinline__ void ex(f32x16_t& sa, f32x16_t& sb, int e) {
-    float v = __builtin_amdgcn_exp2f(get(sa, sb, e));
+    float v = (ABL & 1) ? get(sa, sb, e) * 0.5f : __builtin_amdgcn_exp2f(get(sa, sb, e));
     PIN(v);
     if (e < 16) sa[e] = v;
     else sb[e - 16] = v;
@@ -96,8 +120,10 @@ struct ExpSumPack {        // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, 
   __device__ __forceinline__ float total() const { return (rs[0] + rs[1]) + (rs[2] + rs[3]); }
 };
 
-template <int DEFER>
-__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk) {
+// ABL (timing ablations, numerically meaningless, AM_ATTN_ABLATIONS builds only): 1 = no exp, 2 = no row max,
+// 4 = no barrier / DMA drain, 8 = no exp/sum/pack at all, 16 = no LDS fragment reads (stale registers)
+template <int DEFER, int ABL = 0, bool PROF = false>
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = __builtin_amdgcn_workitem_id_x();
   const int lane = tid & 63;
@@ -107,6 +133,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   const int head = bh % p.heads, seq = bh / p.heads;
   const int q0 = __builtin_amdgcn_workgroup_id_x() * QBLK + wave * 64;
   const float c = p.scale * 1.4426950408889634f;
+  // PROF: s_memtime stamps of workgroup (0,0), tiles 64..71: prof[wave][tile - 64][slot]
+  auto stamp = [&](int g, int slot) __attribute__((always_inline)) {
+    if (PROF && __builtin_amdgcn_workgroup_id_x() == 0 && bh == 0 && g >= 64 && g < 72) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+      if (lane == 0) prof[(wave * 8 + (g - 64)) * 8 + slot] = t;
+    }
+  };
 
   // ---- Q fragments (B operand) of both query blocks, pre-scaled to log2 units, parked in a[128:191] ----
 #pragma unroll
@@ -130,19 +164,28 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   const bf16_t* v_lane = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;   // + i * 32 rows
   const int64_t v_step = (int64_t)32 * p.sk_pad;
   const int n_tiles = p.nchunks * tiles_per_chunk;
-  int d_tt = 0;
-  int64_t d_chunk = 0;
-  auto dma_tile = [&](int stage) __attribute__((always_inline)) {
-    unsigned char* kdst = smem + stage * STAGE_B + wave * 1024;
-    const bf16_t* ks = k_lane + d_chunk + (int64_t)d_tt * (KVBLK * HD);
-    const bf16_t* vs = v_lane + d_chunk + (int64_t)d_tt * KVBLK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + i * 16 * HD), (lds_ptr_t)(kdst + i * 4096), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + i * v_step), (lds_ptr_t)(kdst + SUB_B + i * 4096), 16, 0, 0);
-    if (++d_tt == tiles_per_chunk) { d_tt = 0; d_chunk += p.chunk_stride; }
+  // Two cursors over the key stream (nchunks x tiles_per_chunk tiles): K runs three tiles ahead of the tile being
+  // softmaxed, V^T two.  Past the end a cursor keeps re-fetching the last tile into the ring slots of the tiles
+  // that do not exist (read only by the discarded QK^T of the last iteration), so every iteration issues exactly
+  // 8 pieces and the loop's wait is a constant vmcnt(8): "all but the previous iteration's pieces have landed".
+  struct Cursor { int j, t, tt; int64_t off; };   // pieces issued so far / 4 (= ring slot), source tile, tile in chunk, chunk offset
+  Cursor kcur{0, 0, 0, 0}, vcur{0, 0, 0, 0};
+  auto advance = [&](Cursor& cu) __attribute__((always_inline)) {
+    ++cu.j;
+    if (cu.t + 1 < n_tiles) {
+      ++cu.t;
+      if (++cu.tt == tiles_per_chunk) { cu.tt = 0; cu.off += p.chunk_stride; }
+    }
+  };
+  auto dma_k = [&](int i) __attribute__((always_inline)) {      // piece i of 4 of the next K tile -> ring slot j & 3
+    unsigned char* dst = smem + (kcur.j & 3) * STAGE_B + wave * 1024 + i * 4096;
+    const bf16_t* src = k_lane + kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  };
+  auto dma_v = [&](int i) __attribute__((always_inline)) {
+    unsigned char* dst = smem + (vcur.j & 3) * STAGE_B + SUB_B + wave * 1024 + i * 4096;
+    const bf16_t* src = v_lane + vcur.off + (int64_t)vcur.tt * KVBLK + i * v_step;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   };
 
   // fragment read offsets (bytes) inside a ring stage
@@ -151,10 +194,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) v_off[kk] = SUB_B + l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  bf16x8_t stale = __builtin_bit_cast(bf16x8_t, u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
+  PIN(stale);
   auto k_frag = [&](const unsigned char* st, int kb, int ks) __attribute__((always_inline)) {
+    if (ABL & 128) return stale;
+    if (ABL & 16) st = smem;
     return *reinterpret_cast<const bf16x8_t*>(st + kb * 32 * 256 + k_off[ks]);
   };
   auto v_frag = [&](const unsigned char* st, int d, int kk) __attribute__((always_inline)) {
+    if (ABL & 128) return stale;
+    if (ABL & 16) st = smem;
     return *reinterpret_cast<const bf16x8_t*>(st + d * 32 * 128 + v_off[kk]);
   };
 
@@ -164,7 +213,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   u32x4_t p0[2][4];          // block 0 P (bf16 pairs): P(g-1) in p0[cur], P(g) born in p0[cur^1]
   u32x4_t p1[4];             // block 1 P: P(g-1) consumed in phase 1, P(g) born in phase 2 (same registers)
   f32x16_t negm[2];          // -m_run splat: C operand of the first k-step
-  bf16x8_t vq[4];            // V^T fragments of the next P.V step (prefetched across the barrier)
+  bf16x8_t vf[2][4];         // V^T fragments, two sets: k-step kk of P.V reads vf[kk & 1] while vf[~kk & 1] is being loaded
+  bf16x8_t kf[3][2];         // K fragments, three sets: k-step ks of QK^T reads kf[ks % 3], loads go two steps ahead
   float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
   float off1 = 0.f;
   bool pend1 = false;
@@ -181,8 +231,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   for (int kk = 0; kk < 4; ++kk) { PIN(p0[0][kk]); PIN(p0[1][kk]); PIN(p1[kk]); }
 
   // ---- prologue: tiles 0 and 1 in flight; V^T of ring stage 3 zeroed (iteration 0 multiplies it by P = 0) ----
-  dma_tile(0);
-  if (n_tiles > 1) dma_tile(1);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {                 // K(0..2), V^T(0..1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_k(i);
+    advance(kcur);
+    if (t < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_v(i);
+      advance(vcur);
+    }
+  }
   {
     unsigned char* z = smem + 3 * STAGE_B + SUB_B + tid * 64;
 #pragma unroll
@@ -194,44 +253,60 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8_t kf = k_frag(smem, kb, ks);
-        if (ks == 0) { s0[kb] = qk_mfma_first(ks, kf, negm[0]); s1c[kb] = qk_mfma_first(8 + ks, kf, negm[1]); }
-        else { qk_mfma_acc(ks, kf, s0[kb]); qk_mfma_acc(8 + ks, kf, s1c[kb]); }
+        const bf16x8_t kfr = k_frag(smem, kb, ks);
+        if (ks == 0) { s0[kb] = qk_mfma_first(ks, kfr, negm[0]); s1c[kb] = qk_mfma_first(8 + ks, kfr, negm[1]); }
+        else { qk_mfma_acc(ks, kfr, s0[kb]); qk_mfma_acc(8 + ks, kfr, s1c[kb]); }
       }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) vq[d] = v_frag(smem + 3 * STAGE_B, d, 0);
+    for (int d = 0; d < 4; ++d) vf[0][d] = v_frag(smem + 3 * STAGE_B, d, 0);
     asm volatile("" :: "v"(negm[0]), "v"(negm[1]));     // SrcC of the first k-step stays allocated until here
   };
 
   // ---- one tile.  cur = ping-pong set holding S(g) of block 1 and P(g-1) of block 0 ----
   auto iteration = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
                        u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
-    dma_drain_barrier();                       // tile g+1 landed; every wave is done with ring stage (g+2)&3
-    if (g + 2 < n_tiles) dma_tile((g + 2) & 3);
+    stamp(g, 0);
+    if (!(ABL & 4)) {                          // all but the previous iteration's 8 pieces have landed (K(g+1), V^T(g));
+      // every wave is done with the slots this iteration refills.  (Not __syncthreads(): its fence drains vmcnt.)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    stamp(g, 1);
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
     const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
     const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
     const bool first = g == 0;
-    bf16x8_t vn[4], kq[2][2];
     RowMax rm;
-    ExpSumPack es;
+    ExpSumPackT<ABL> es;
 
-    // ===== phase 1a: first 8 P.V MFMAs || row max of block 0 =====
+    constexpr EsTab ES = es_make_tab();
+    auto es_gap = [&](int gap, f32x16_t& sa, f32x16_t& sb, u32x4_t (&w)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = ES.lo[gap]; n < ES.lo[gap + 1]; ++n) es.step(n, sa, sb, w);
+    };
+    auto bf = [](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
+    // ===== phase 1a: first 8 P.V MFMAs (k-step 0) || row max of block 0; K(g+3) DMA =====
+    stamp(g, 2);
     FENCE();
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      pv_mfma(d, vq[d], __builtin_bit_cast(bf16x8_t, p0c[0]));
-      vn[d] = v_frag(v_st, d, 1);
+      pv_mfma(d, vf[0][d], bf(p0c[0]));
+      dma_k(d);                                               // one LDS-DMA piece per MFMA pair
+      if (d < 2) vf[1][2 * d] = v_frag(v_st, 2 * d, 1);       // the next k-step's fragments: issued in gaps 0..3
 #pragma unroll
-      for (int n = (20 * (2 * d) + 7) / 8; n < (20 * (2 * d + 1) + 7) / 8; ++n) rm.step(n, s0[0], s0[1]);
+      for (int n = (20 * (2 * d) + 7) / 8; n < (20 * (2 * d + 1) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
       FENCE();
-      pv_mfma(4 + d, vq[d], __builtin_bit_cast(bf16x8_t, p1[0]));
+      pv_mfma(4 + d, vf[0][d], bf(p1[0]));
+      if (d < 2) vf[1][2 * d + 1] = v_frag(v_st, 2 * d + 1, 1);
 #pragma unroll
-      for (int n = (20 * (2 * d + 1) + 7) / 8; n < (20 * (2 * d + 2) + 7) / 8; ++n) rm.step(n, s0[0], s0[1]);
+      for (int n = (20 * (2 * d + 1) + 7) / 8; n < (20 * (2 * d + 2) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
       FENCE();
     }
+    HOLD4(vf[0][0], vf[0][1], vf[0][2], vf[0][3]);
+    stamp(g, 3);
+    advance(kcur);
     bool flag0 = false;
     float alpha0 = 1.f;
+    if (ABL & 2) rm.mx = 0.f;
     if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 0, re-base its scores
       const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
       alpha0 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
@@ -241,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       for (int r = 0; r < 16; ++r) { s0[0][r] -= delta; s0[1][r] -= delta; negm[0][r] = -m_run[0]; }
       flag0 = true;
     }
-    // ===== phase 1b: 24 P.V MFMAs || exp / row sum / bf16 pack of block 0; K(g+1) prefetch =====
+    // ===== phase 1b: 24 P.V MFMAs (k-steps 1..3) || exp / row sum / bf16 pack of block 0; K(g+1) prefetch =====
     es.init();
     FENCE();
 #pragma unroll
@@ -249,19 +324,25 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int gap = ((kk - 1) * 4 + d) * 2;
-        vq[d] = vn[d];
-        pv_mfma(d, vq[d], __builtin_bit_cast(bf16x8_t, p0c[kk]));
-        if (kk < 3) vn[d] = v_frag(v_st, d, kk + 1);
-        else kq[d >> 1][d & 1] = k_frag(k_st, d & 1, d >> 1);
-#pragma unroll
-        for (int n = (80 * gap + 23) / 24; n < (80 * (gap + 1) + 23) / 24; ++n) es.step(n, s0[0], s0[1], p0n);
+        pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
+        if (d < 2) {                            // next fragments in gaps 0..3 of the step: landed by its end
+          if (kk < 3) vf[(kk + 1) & 1][2 * d] = v_frag(v_st, 2 * d, kk + 1);
+          else kf[d][0] = k_frag(k_st, 0, d);
+        }
+        if (!(ABL & (8 | 32))) es_gap(gap, s0[0], s0[1], p0n);
         FENCE();
-        pv_mfma(4 + d, vq[d], __builtin_bit_cast(bf16x8_t, p1[kk]));
-#pragma unroll
-        for (int n = (80 * (gap + 1) + 23) / 24; n < (80 * (gap + 2) + 23) / 24; ++n) es.step(n, s0[0], s0[1], p0n);
+        pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
+        if (d < 2) {
+          if (kk < 3) vf[(kk + 1) & 1][2 * d + 1] = v_frag(v_st, 2 * d + 1, kk + 1);
+          else kf[d][1] = k_frag(k_st, 1, d);
+        }
+        if (!(ABL & (8 | 32))) es_gap(gap + 1, s0[0], s0[1], p0n);
         FENCE();
       }
+      HOLD4(vf[kk & 1][0], vf[kk & 1][1], vf[kk & 1][2], vf[kk & 1][3]);
+      HOLD2(p0c[kk - 1], p1[kk - 1]);
     }
+    stamp(g, 4);
     l_run[0] += es.total();
     if (flag0) o_scale(0, alpha0);             // rare: O of block 0 is complete through tile g-1 only now
     if (pend1) {                               // rare: S(g) of block 1 was born before block 1's last re-base
@@ -270,27 +351,32 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       pend1 = false;
     }
 
-    // ===== phase 2a: first 8 QK^T MFMAs || row max of block 1 =====
+    // ===== phase 2a: first 8 QK^T MFMAs (k-steps 0, 1) || row max of block 1; V^T(g+2) DMA =====
     FENCE();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int gap = (ks * 2 + kb) * 2;
-        const bf16x8_t kf = kq[ks][kb];
-        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf, negm[0]);
-        else qk_mfma_acc(ks, kf, s0[kb]);
+        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks][kb], negm[0]);
+        else qk_mfma_acc(ks, kf[ks][kb], s0[kb]);
+        dma_v(ks * 2 + kb);
 #pragma unroll
-        for (int n = (20 * gap + 7) / 8; n < (20 * (gap + 1) + 7) / 8; ++n) rm.step(n, s1c[0], s1c[1]);
+        for (int n = (20 * gap + 7) / 8; n < (20 * (gap + 1) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
         FENCE();
-        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf, negm[1]);
-        else qk_mfma_acc(8 + ks, kf, s1n[kb]);
-        kq[ks][kb] = k_frag(k_st, kb, ks + 2);
+        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks][kb], negm[1]);
+        else qk_mfma_acc(8 + ks, kf[ks][kb], s1n[kb]);
+        kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);       // into the set the previous k-step has finished with
 #pragma unroll
-        for (int n = (20 * (gap + 1) + 7) / 8; n < (20 * (gap + 2) + 7) / 8; ++n) rm.step(n, s1c[0], s1c[1]);
+        for (int n = (20 * (gap + 1) + 7) / 8; n < (20 * (gap + 2) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
         FENCE();
       }
+      HOLD2(kf[ks][0], kf[ks][1]);
+      if (ks == 0) HOLD2(p0c[3], p1[3]);
     }
+    advance(vcur);
+    stamp(g, 5);
+    if (ABL & 2) rm.mx = 0.f;
     if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 1
       const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
       const float a1 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
@@ -302,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       pend1 = true;
       o_scale(1, a1);
     }
-    // ===== phase 2b: 24 QK^T MFMAs || exp / row sum / bf16 pack of block 1; V^T(g) prefetch =====
+    // ===== phase 2b: 24 QK^T MFMAs (k-steps 2..7) || exp / row sum / bf16 pack of block 1; V^T(g) prefetch =====
     es.init();
     FENCE();
 #pragma unroll
@@ -310,19 +396,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int gap = ((ks - 2) * 2 + kb) * 2;
-        const bf16x8_t kf = kq[ks & 1][kb];
-        qk_mfma_acc(ks, kf, s0[kb]);
-#pragma unroll
-        for (int n = (80 * gap + 23) / 24; n < (80 * (gap + 1) + 23) / 24; ++n) es.step(n, s1c[0], s1c[1], p1);
+        qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
+        if (!(ABL & (8 | 64))) es_gap(gap, s1c[0], s1c[1], p1);
         FENCE();
-        qk_mfma_acc(8 + ks, kf, s1n[kb]);
-        if (ks < 6) kq[ks & 1][kb] = k_frag(k_st, kb, ks + 2);
-        else vq[(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
-#pragma unroll
-        for (int n = (80 * (gap + 1) + 23) / 24; n < (80 * (gap + 2) + 23) / 24; ++n) es.step(n, s1c[0], s1c[1], p1);
+        qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
+        if (ks < 6) kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);
+        else vf[0][(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
+        if (!(ABL & (8 | 64))) es_gap(gap + 1, s1c[0], s1c[1], p1);
         FENCE();
       }
+      HOLD2(kf[ks % 3][0], kf[ks % 3][1]);
     }
+    stamp(g, 6);
     l_run[1] += es.total();
   };
 
@@ -343,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   // The last iteration's QK^T MFMAs (scores of a tile that does not exist) are still in flight and hipcc does
   // not know they are MFMAs: hold their destination registers until the results have landed, or the epilogue's
   // temporaries allocated there are overwritten (MFMA D -> any writer: 12 wait states).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA piece may outlive the workgroup's LDS allocation
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0][0]), "+v"(s1[0][1]), "+v"(s1[1][0]), "+v"(s1[1][1]));
 
   // ---- drain: O += V^T(n-1) P^T(n-1)  (P of block 0 is in p0[0] after an odd-set iteration) ----
@@ -352,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const bf16x8_t vfr = kk == 0 ? vq[d] : v_frag(v_st, d, kk);
+        const bf16x8_t vfr = kk == 0 ? vf[0][d] : v_frag(v_st, d, kk);
         pv_mfma(d, vfr, __builtin_bit_cast(bf16x8_t, p0[0][kk]));
         pv_mfma(4 + d, vfr, __builtin_bit_cast(bf16x8_t, p1[kk]));
       }
@@ -393,19 +479,49 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 }  // namespace
 
 // Main (non-split) grid of the 4x64 kernel: query blocks [0, nblk_main) of every (sequence, head).
-int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
+template <int DEFER, int ABL>
+static int launch64(const am_attn_args* a, int tiles_per_chunk, int nblk_main, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<0>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
     attr_set = true;
   }
-  const dim3 grid(nblk_main, a->nseq * a->heads);
-  if (defer == 0)
-    hipLaunchKernelGGL((attn_fwd64_kernel<0>), grid, dim3(256), NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk);
-  else
-    hipLaunchKernelGGL((attn_fwd64_kernel<8>), grid, dim3(256), NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk);
+  hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL>), dim3(nblk_main, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
+                     (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr);
   return AM_OK;
 }
+int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
+#ifdef AM_ATTN_ABLATIONS
+  switch (a->defer_log2) {     // 3000 + ABL: timing ablations (tools/kernel_bench.py --ablate64)
+    case 3001: return launch64<8, 1>(a, tiles_per_chunk, nblk_main, stream);
+    case 3002: return launch64<8, 2>(a, tiles_per_chunk, nblk_main, stream);
+    case 3004: return launch64<8, 4>(a, tiles_per_chunk, nblk_main, stream);
+    case 3008: return launch64<8, 8>(a, tiles_per_chunk, nblk_main, stream);
+    case 3010: return launch64<8, 10>(a, tiles_per_chunk, nblk_main, stream);
+    case 3014: return launch64<8, 14>(a, tiles_per_chunk, nblk_main, stream);
+    case 3016: return launch64<8, 16>(a, tiles_per_chunk, nblk_main, stream);
+    case 3030: return launch64<8, 30>(a, tiles_per_chunk, nblk_main, stream);
+    case 3032: return launch64<8, 32>(a, tiles_per_chunk, nblk_main, stream);
+    case 3064: return launch64<8, 64>(a, tiles_per_chunk, nblk_main, stream);
+    case 3128: return launch64<8, 128>(a, tiles_per_chunk, nblk_main, stream);
+    case 3132: return launch64<8, 132>(a, tiles_per_chunk, nblk_main, stream);
+    case 3142: return launch64<8, 142>(a, tiles_per_chunk, nblk_main, stream);
+    default: break;
+  }
+#endif
+  return defer == 0 ? launch64<0, 0>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0>(a, tiles_per_chunk, nblk_main, stream);
+}
+
+#ifdef AM_ATTN_ABLATIONS
+// per-phase s_memtime stamps of workgroup (0,0): prof[4 waves][8 tiles (64..71)][8 slots]  (tools/attn_profile.py --k64)
+extern "C" int am_attention64_profile(const am_attn_args* a, unsigned long long* prof_dev, void* stream) {
+  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
+  const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
+  hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, true>), dim3(ceil_div(a->sq, QBLK), a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
+                     (hipStream_t)stream, *a, tiles_per_chunk, prof_dev);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+#endif

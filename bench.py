@@ -110,7 +110,7 @@ def attention_roofline(T, N, H, dev, world=1, reps=3):
     if world == 1 and (T, N, H) == (16, 4096, 8) and os.path.exists(tj):
         with open(tj) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
-    return {"bound": "mfma", "kernel": "attn_fwd_kernel (inflated self-attention, 1 launch = 1 layer on this rank)",
+    return {"bound": "mfma", "kernel": "attn_fwd64_kernel (inflated self-attention, 1 launch = 1 layer on this rank; timed with its split-tail kernels)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "launch_ms": round(sec * 1e3, 3), "flops_per_launch": flops}

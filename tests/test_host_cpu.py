@@ -145,3 +145,39 @@ def test_perm16_is_an_involution_matching_the_mfma_layout():
     for hi in range(2):
         for j in range(8):
             assert int(idx[hi * 8 + j]) == (j & 3) + 8 * (j >> 2) + 4 * hi
+
+
+def test_attn64_register_audit(tmp_path):
+    """The 4x64 attention kernel names AccVGPRs a[0:191] literally in inline asm (O accumulators, Q fragments).
+    That is only sound if hipcc itself never touches the accumulator file in that kernel: no spills, exactly the
+    192 registers the asm statements clobber, and every v_accvgpr_* / AGPR MFMA inside an ASMSTART/ASMEND pair
+    (tools/gen_attn64_asm.py; cdna guide 'keep out of registers you name')."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "actionmesh_amd", "csrc", "am_attention64.hip")
+    out = tmp_path / "a64.s"
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mno-amdgpu-ieee", "-fno-honor-nans",
+             "--cuda-device-only", "-S", "-o", str(out), src]
+    subprocess.run([hipcc] + flags, check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"\.agpr_count:\s+(\d+)\n\s+\.name:\s+(\S*attn_fwd64_kernel\S*)\n\s+\.private_segment_fixed_size:\s+(\d+)", text)
+    if not kernels:   # field order differs between compiler versions: fall back to independent searches
+        names = re.findall(r"\.name:\s+(\S*attn_fwd64_kernel\S*)", text)
+        assert names, "no attn_fwd64_kernel in the assembly"
+        kernels = [(a, n, p) for a, n, p in zip(re.findall(r"\.agpr_count:\s+(\d+)", text), names,
+                                                re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))]
+    for agprs, name, scratch in kernels:
+        assert int(agprs) == 192, f"{name}: {agprs} AccVGPRs allocated, the asm owns exactly 192"
+        assert int(scratch) == 0, f"{name}: spills ({scratch} B of scratch)"
+    in_asm = False
+    for ln in text.splitlines():
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        elif not in_asm and re.search(r"\bv_accvgpr_|\ba\[\d+:\d+\]|\ba\d+\b", ln.split(";")[0]) and ln.strip().startswith("v_"):
+            raise AssertionError(f"compiler-generated AccVGPR access outside inline asm: {ln.strip()}")

@@ -240,7 +240,8 @@ def _sdpa_ref(q, k, v):
                                                   (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1),
                                                   # short last query block -> split-KV tail path (+ chunks)
                                                   (1, 2, 2320, 4200, 1), (2, 1, 2305, 4224, 2), (1, 1, 2432, 4097, 1)])
-@pytest.mark.parametrize("defer", [0, 8, 58, 78, 60, 68])  # 58: 2 x 4-wave geometry, 78: balanced two-phase, 60/68: 4 waves x 64 rows
+# 0/8: product dispatch; 60/68: forced 4 waves x 64 rows; 90/98: forced 8-wave kernel; 58: 2 x 4-wave geometry; 78: balanced two-phase
+@pytest.mark.parametrize("defer", [0, 8, 60, 68, 90, 98, 58, 78])
 def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     from actionmesh_amd import ops
     q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)
@@ -267,12 +268,13 @@ def test_attention_forced_rescale_branch(dev):
     q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
     Q, K, Vt, skc = _layout(q, k, v, 1)
     ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(sq, 128)
-    outs = []
-    for defer in (0, 8):
-        o = ops.attention(Q, K, Vt, sq, skc, defer_log2=defer).float()
-        assert (o - ref).abs().max().item() < 3e-2, f"defer={defer}"
-        outs.append(o)
-    assert (outs[0] - outs[1]).abs().max().item() < 3e-2
+    for base in (0, 60, 90):          # product dispatch, forced 4x64 kernel, forced 8-wave kernel
+        outs = []
+        for defer in (base, base + 8):
+            o = ops.attention(Q, K, Vt, sq, skc, defer_log2=defer).float()
+            assert (o - ref).abs().max().item() < 3e-2, f"defer={defer}"
+            outs.append(o)
+        assert (outs[0] - outs[1]).abs().max().item() < 3e-2
 
 
 def test_attention_properties_full_size(dev):

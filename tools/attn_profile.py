@@ -14,6 +14,25 @@ a = L.AmAttnArgs()
 a.Q, a.K, a.Vt, a.O = Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr()
 a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = B, H, S, Q.shape[2], S, K.shape[2]
 a.nchunks = 1; a.chunk_stride = 0; a.ldo = H * 128; a.scale = 128 ** -0.5; a.defer_log2 = 8
+if "--k64" in sys.argv:
+    prof = torch.zeros(4 * 8 * 8, dtype=torch.int64, device=dev)
+    lib = C.CDLL(L.LIB_PATH)
+    lib.am_attention64_profile.argtypes = [C.POINTER(L.AmAttnArgs), C.c_void_p, C.c_void_p]
+    for _ in range(2):
+        rc = lib.am_attention64_profile(C.byref(a), prof.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    p = prof.cpu().view(4, 8, 8)
+    print("4x64 kernel, workgroup (0,0), cycles (s_memtime): barrier | dma issue | 1a (8 PV + row max 0) | branch+1b (24 PV + exp 0) | "
+          "2a (8 QK + row max 1) | branch+2b (24 QK + exp 1) | loop tail")
+    for w in range(4):
+        print(f"wave {w}:")
+        for t in range(0, 7):
+            r = p[w, t]; nxt = p[w, t + 1, 0]
+            print(f"  tile {64 + t}: barrier {int(r[1]-r[0]):5d} | dma {int(r[2]-r[1]):4d} | 1a {int(r[3]-r[2]):5d} | 1b {int(r[4]-r[3]):5d} | "
+                  f"2a {int(r[5]-r[4]):5d} | 2b {int(r[6]-r[5]):5d} | tail {int(nxt-r[6]):4d} | total {int(nxt-r[0]):5d}")
+    print("barrier-exit skew (tile 66):", [int(p[w, 2, 1] - p[0, 2, 1]) for w in range(4)])
+    sys.exit(0)
 prof = torch.zeros(8 * 8 * 6, dtype=torch.int64, device=dev)
 lib = C.CDLL(L.LIB_PATH)
 lib.am_attention_profile.argtypes = [C.POINTER(L.AmAttnArgs), C.c_void_p, C.c_void_p]

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--defer", type=int, default=8)
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
+    ap.add_argument("--ablate64", action="store_true", help="time the 4x64 kernel's ablations (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
     a = ap.parse_args()
     T, N, C, H, S = (16, 4096, 1024, 8, 257) if a.shape == "headline" else (16, 2048, 2048, 16, 257)
@@ -45,12 +46,18 @@ def main():
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
         fl = 4.0 * Sq * Sq * C * B
-        for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64"), (a.defer + 70, "balanced"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
+        for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64"), (a.defer + 90, "8-wave"), (a.defer + 70, "balanced"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
                       (a.defer + 100, "staggered")):
             if d >= 100 and not a.variants:
                 continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:12s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if a.ablate64:
+            for k, nm in {1: "no exp", 2: "no row max", 4: "no barrier / DMA drain", 8: "no exp/sum/pack", 10: "no softmax VALU",
+                          14: "no softmax VALU, no barrier", 16: "no LDS fragment addressing (same stage)", 30: "MFMA + fragment reads only", 32: "no exp/sum/pack beside P.V (phase 1b)", 64: "no exp/sum/pack beside QK^T (phase 2b)", 128: "no LDS fragment reads", 132: "no LDS reads, no barrier",
+                          142: "no LDS reads, no barrier, no softmax VALU"}.items():
+                ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=3000 + k), a.reps)
+                print(f"  4x64 ablation {nm:42s}: {ms:8.3f} ms  ({fl / ms / 1e9:7.1f} TF-equivalent)")
         if a.ablate:
             for k, nm in {1: "no exp", 2: "no row max", 3: "no row sum", 4: "no cvt", 5: "V frags not prefetched",
                           6: "no softmax VALU at all"}.items():
@@ -67,9 +74,13 @@ def main():
         BT = B * T
         Q = rnd(BT, H, ops.round_up(L, 256), 128); K = rnd(BT, H, ops.round_up(S, 64), 128)
         Vt = rnd(BT, H, 128, ops.round_up(S, 64)); out = torch.empty((BT * L, C), dtype=torch.bfloat16, device=dev)
-        ms = timeit(lambda: ops.attention(Q, K, Vt, L, S, out=out, defer_log2=a.defer), a.reps)
         fl = 4.0 * BT * L * S * C
-        print(f"cross-attn BT={BT} H={H} L={L} S={S}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64"), (a.defer + 90, "8-wave")):
+            try:
+                ms = timeit(lambda: ops.attention(Q, K, Vt, L, S, out=out, defer_log2=d), a.reps)
+            except RuntimeError:
+                continue
+            print(f"cross-attn BT={BT} H={H} L={L} S={S} variant={d:3d} ({nm:8s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         del Q, K, Vt, out
     if "gemm" in only:
         F_ = 4 * C

@@ -50,6 +50,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 
 // ---- softmax of one 32-query block, cut into single-instruction steps that the phases thread through their
 //      MFMA gaps.  sa/sb = the block's scores for keys 0-31 / 32-63 of the tile (already relative to m_run). ----
+// The 20 row-max steps go into the first 7 of a phase-a's 8 MFMA gaps: the dependent tail (swap, final max) must
+// be out of the way when the last MFMA issues, so that only the compare + branch separate it from phase b's first.
+__device__ __host__ constexpr int rm_lo(int gap) { return gap >= 7 ? 20 : (20 * gap + 6) / 7; }
 struct RowMax {            // 20 steps: four v_max3 chains, cross-half swap
   float a[4];
   float mx;
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   auto iteration = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
                        u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
     stamp(g, 0);
+    if (g > 0) { advance(kcur); advance(vcur); }   // past the pieces issued in the previous iteration (scalar work, parked at the barrier)
     if (!(ABL & 4)) {                          // all but the previous iteration's 8 pieces have landed (K(g+1), V^T(g));
       // every wave is done with the slots this iteration refills.  (Not __syncthreads(): its fence drains vmcnt.)
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -293,17 +297,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       dma_k(d);                                               // one LDS-DMA piece per MFMA pair
       if (d < 2) vf[1][2 * d] = v_frag(v_st, 2 * d, 1);       // the next k-step's fragments: issued in gaps 0..3
 #pragma unroll
-      for (int n = (20 * (2 * d) + 7) / 8; n < (20 * (2 * d + 1) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
+      for (int n = rm_lo(2 * d); n < rm_lo(2 * d + 1); ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
       FENCE();
       pv_mfma(4 + d, vf[0][d], bf(p1[0]));
       if (d < 2) vf[1][2 * d + 1] = v_frag(v_st, 2 * d + 1, 1);
 #pragma unroll
-      for (int n = (20 * (2 * d + 1) + 7) / 8; n < (20 * (2 * d + 2) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
+      for (int n = rm_lo(2 * d + 1); n < rm_lo(2 * d + 2); ++n) if (!(ABL & 2)) rm.step(n, s0[0], s0[1]);
       FENCE();
     }
     HOLD4(vf[0][0], vf[0][1], vf[0][2], vf[0][3]);
     stamp(g, 3);
-    advance(kcur);
     bool flag0 = false;
     float alpha0 = 1.f;
     if (ABL & 2) rm.mx = 0.f;
@@ -340,7 +343,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         FENCE();
       }
       HOLD4(vf[kk & 1][0], vf[kk & 1][1], vf[kk & 1][2], vf[kk & 1][3]);
-      HOLD2(p0c[kk - 1], p1[kk - 1]);
     }
     stamp(g, 4);
     l_run[0] += es.total();
@@ -362,19 +364,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         else qk_mfma_acc(ks, kf[ks][kb], s0[kb]);
         dma_v(ks * 2 + kb);
 #pragma unroll
-        for (int n = (20 * gap + 7) / 8; n < (20 * (gap + 1) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
+        for (int n = rm_lo(gap); n < rm_lo(gap + 1); ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
         FENCE();
         if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks][kb], negm[1]);
         else qk_mfma_acc(8 + ks, kf[ks][kb], s1n[kb]);
         kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);       // into the set the previous k-step has finished with
 #pragma unroll
-        for (int n = (20 * (gap + 1) + 7) / 8; n < (20 * (gap + 2) + 7) / 8; ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
+        for (int n = rm_lo(gap + 1); n < rm_lo(gap + 2); ++n) if (!(ABL & 2)) rm.step(n, s1c[0], s1c[1]);
         FENCE();
       }
       HOLD2(kf[ks][0], kf[ks][1]);
-      if (ks == 0) HOLD2(p0c[3], p1[3]);
     }
-    advance(vcur);
     stamp(g, 5);
     if (ABL & 2) rm.mx = 0.f;
     if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 1

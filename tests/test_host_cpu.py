@@ -181,7 +181,7 @@ def test_attn64_register_audit(tmp_path):
             in_asm = True
         elif "#ASMEND" in ln:
             in_asm = False
-        elif not in_asm and code.strip().startswith("v_"):
+        elif not in_asm and re.match(r"\s+(v_|ds_|global_|buffer_|scratch_|flat_)", code):
             for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", code):
                 lo = int(m.group(1) if m.group(1) is not None else m.group(3))
                 assert lo >= 192, f"compiler-generated access to an asm-owned AccVGPR: {ln.strip()}"

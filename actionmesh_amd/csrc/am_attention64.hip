@@ -159,18 +159,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   o_zero();
 
   // ---- LDS-DMA: 16-byte unit U = i*256 + wave*64 + lane of a 1024-unit tile operand, i = 0..3 ----
+  // Source address = wave-uniform base (scalar registers: operand base + tile + piece) + a 32-bit per-lane byte
+  // offset, so hipcc selects the saddr form of global_load_lds and a piece costs no VALU address arithmetic.
   const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
   const int x = wave * 64 + lane;
   const int kr = x >> 4, kc = (x & 15) ^ (kr & 15);
-  const bf16_t* k_lane = p.K + (int64_t)bh * k_seq_stride + kr * HD + kc * 8;                    // + i * 16 rows
+  const unsigned k_lane_off = (unsigned)(kr * HD + kc * 8) * 2u;                       // bytes; + i * 16 rows (uniform)
   const int vr = x >> 3, vc = (x & 7) ^ ((vr >> 1) & 7);
-  const bf16_t* v_lane = p.Vt + (int64_t)bh * k_seq_stride + (int64_t)vr * p.sk_pad + vc * 8;   // + i * 32 rows
-  const int64_t v_step = (int64_t)32 * p.sk_pad;
+  const unsigned v_lane_off = ((unsigned)vr * (unsigned)p.sk_pad + (unsigned)vc * 8u) * 2u;   // bytes; + i * 32 rows (uniform)
+  const char* k_base = reinterpret_cast<const char*>(p.K + (int64_t)bh * k_seq_stride);
+  const char* v_base = reinterpret_cast<const char*>(p.Vt + (int64_t)bh * k_seq_stride);
+  const int64_t v_step = (int64_t)32 * p.sk_pad * 2;                                          // bytes
   const int n_tiles = p.nchunks * tiles_per_chunk;
-  // Two cursors over the key stream (nchunks x tiles_per_chunk tiles): K runs three tiles ahead of the tile being
-  // softmaxed, V^T two.  Past the end a cursor keeps re-fetching the last tile into the ring slots of the tiles
-  // that do not exist (read only by the discarded QK^T of the last iteration), so every iteration issues exactly
-  // 8 pieces and the loop's wait is a constant vmcnt(8): "all but the previous iteration's pieces have landed".
   struct Cursor { int j, t, tt; int64_t off; };   // pieces issued so far / 4 (= ring slot), source tile, tile in chunk, chunk offset
   Cursor kcur{0, 0, 0, 0}, vcur{0, 0, 0, 0};
   auto advance = [&](Cursor& cu) __attribute__((always_inline)) {
@@ -180,15 +180,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       if (++cu.tt == tiles_per_chunk) { cu.tt = 0; cu.off += p.chunk_stride; }
     }
   };
+  auto uniform = [](const char* q) __attribute__((always_inline)) {      // pin a wave-uniform pointer to scalar registers
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
   auto dma_k = [&](int i) __attribute__((always_inline)) {      // piece i of 4 of the next K tile -> ring slot j & 3
     unsigned char* dst = smem + (kcur.j & 3) * STAGE_B + wave * 1024 + i * 4096;
-    const bf16_t* src = k_lane + kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    const char* src = uniform(k_base + (kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD) * 2);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + k_lane_off), (lds_ptr_t)dst, 16, 0, 0);
   };
   auto dma_v = [&](int i) __attribute__((always_inline)) {
     unsigned char* dst = smem + (vcur.j & 3) * STAGE_B + SUB_B + wave * 1024 + i * 4096;
-    const bf16_t* src = v_lane + vcur.off + (int64_t)vcur.tt * KVBLK + i * v_step;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    const char* src = uniform(v_base + (vcur.off + (int64_t)vcur.tt * KVBLK) * 2 + i * v_step);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + v_lane_off), (lds_ptr_t)dst, 16, 0, 0);
   };
 
   // fragment read offsets (bytes) inside a ring stage

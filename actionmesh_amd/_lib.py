@@ -63,6 +63,8 @@ class AmAttnArgs(C.Structure):
         ("sk", C.c_int32), ("sk_pad", C.c_int32), ("nchunks", C.c_int32),
         ("chunk_stride", C.c_int64), ("ldo", C.c_int32), ("scale", C.c_float),
         ("defer_log2", C.c_int32),
+        ("chunk_first", C.c_int32), ("chunk_total", C.c_int32), ("rows", C.c_int32), ("state_mode", C.c_int32),
+        ("state", C.c_void_p),
     ]
 
 
@@ -79,10 +81,11 @@ SYMBOLS = {
     "am_denoise_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "am_forward_begin": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "am_layer_pre_attn": (C.c_int, [_P, C.c_int, _P]),
+    "am_layer_attn_local": (C.c_int, [_P, C.c_int, _P]),
     "am_layer_post_attn": (C.c_int, [_P, C.c_int, _P]),
     "am_forward_end": (C.c_int, [_P, _P, _P]),
     "am_kv_chunk_elems": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
-    "am_bind_kv_buffers": (C.c_int, [_P, _P, _P]),
+    "am_bind_kv_buffers": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "am_flow_step": (C.c_int, [_P, _P, C.c_int, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "am_step_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),

@@ -642,7 +642,19 @@ int launch(const am_attn_args* a, void* stream) {
   static float* part = nullptr;       // library-owned scratch, grown on demand
   static size_t part_elems = 0;
   const size_t need = (size_t)bh * SPLIT_Z * G::QBLK * PART_LD;
-  const bool split = nblk >= 9 && tail_rows <= G::QBLK / 2 && all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
+  // a->rows: 0 = every query block; 1 = only the blocks the 4x64 kernel takes ("main": all but a short last block);
+  // 2 = only what rows = 1 leaves out.  The main/rest boundary depends on the query geometry alone, so the calls of a
+  // two-pass sequence (different nchunks) agree on it.
+  const bool tail_geom = nblk >= 9 && tail_rows <= G::QBLK / 2;
+  const bool can_split = all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
+  const bool split = tail_geom && can_split;
+  if (a->rows == 1) {
+    AM_CHECK(use64, "am_attention_bf16: rows = 1 / two-pass needs the 4x64 kernel (>= 16 key tiles in the chunks walked)");
+    AM_TRY(am_attention64_main(a, tiles_per_chunk, tail_geom ? nblk - 1 : nblk, DEFER, stream));
+    AM_HIP(hipGetLastError());
+    return AM_OK;
+  }
+  if (a->rows == 2 && !tail_geom) return AM_OK;
   if (split && part_elems < need) {
     if (part) AM_HIP(hipFree(part));
     part = nullptr; part_elems = 0;
@@ -650,7 +662,11 @@ int launch(const am_attn_args* a, void* stream) {
     part_elems = need;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (use64)
+  if (a->rows == 2) {
+    if (!split)          // the short last block alone, un-split (key stream too short to cut 16 ways)
+      hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false, NW, NSUB>), dim3(1, bh), dim3(G::THREADS), G::SMEM, st, *a,
+                         tiles_per_chunk, nblk - 1, (float*)nullptr);
+  } else if (use64)
     AM_TRY(am_attention64_main(a, tiles_per_chunk, split ? nblk - 1 : nblk, DEFER, stream));
   else if (BALANCED)
     hipLaunchKernelGGL((attn_fwd_balanced_kernel<DEFER>), dim3(split ? nblk - 1 : nblk, bh), dim3(512), 4 * SUB_B, st, *a,
@@ -695,6 +711,14 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
            "am_attention_bf16: operands misaligned");
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "am_attention_bf16: nseq*heads=%lld exceeds grid.y",
            (long long)a->nseq * a->heads);
+  AM_CHECK(a->rows >= 0 && a->rows <= 2 && a->state_mode >= 0 && a->state_mode <= 2, "am_attention_bf16: bad rows / state_mode");
+  AM_CHECK(a->state_mode == 0 || (a->rows == 1 && a->state != nullptr && (uintptr_t)a->state % 16 == 0),
+           "am_attention_bf16: state_mode needs rows = 1 and a 16-byte aligned state buffer");
+  AM_CHECK(a->chunk_total == 0 || (a->rows == 1 && a->chunk_total > 0 && a->chunk_first >= 0 && a->chunk_first < a->chunk_total &&
+                                   a->nchunks <= a->chunk_total),
+           "am_attention_bf16: chunk_first/chunk_total need rows = 1, 0 <= first < total, nchunks <= total");
+  AM_CHECK(a->rows != 1 || a->defer_log2 == 0 || a->defer_log2 == 8 || a->defer_log2 == 60 || a->defer_log2 == 68,
+           "am_attention_bf16: rows = 1 runs on the product dispatch only");
   switch (a->defer_log2) {
     case 0: return launch<0, 8, 2, 3>(a, stream);
     case 8: return launch<8, 8, 2, 3>(a, stream);

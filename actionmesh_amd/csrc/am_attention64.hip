@@ -125,7 +125,10 @@ struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, 
 
 // ABL (timing ablations, numerically meaningless, AM_ATTN_ABLATIONS builds only): 1 = no exp, 2 = no row max,
 // 4 = no barrier / DMA drain, 8 = no exp/sum/pack at all, 16 = no LDS fragment reads (stale registers)
-template <int DEFER, int ABL = 0, bool PROF = false>
+// STATE (two-pass attention, am_attn_args.state_mode): 0 = one pass; 1 = save the un-normalised (O, m, l) of every row
+// to p.state instead of writing O; 2 = resume from p.state, finish, write O.
+constexpr int STATE_LD = 132;      // floats per saved row: O[128], m, l, pad (16-byte aligned rows)
+template <int DEFER, int ABL = 0, bool PROF = false, int STATE = 0>
 __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = __builtin_amdgcn_workitem_id_x();
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
       for (int e = 0; e < 4; ++e) q_write((j * 8 + ks) * 4 + e, pack_bf2(bflo(raw[e]) * c, bfhi(raw[e]) * c));
     }
   }
-  o_zero();
+  if (STATE != 2) o_zero();
 
   // ---- LDS-DMA: 16-byte unit U = i*256 + wave*64 + lane of a 1024-unit tile operand, i = 0..3 ----
   // Source address = wave-uniform base (scalar registers: operand base + tile + piece) + a 32-bit per-lane byte
@@ -171,13 +174,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   const char* v_base = reinterpret_cast<const char*>(p.Vt + (int64_t)bh * k_seq_stride);
   const int64_t v_step = (int64_t)32 * p.sk_pad * 2;                                          // bytes
   const int n_tiles = p.nchunks * tiles_per_chunk;
-  struct Cursor { int j, t, tt; int64_t off; };   // pieces issued so far / 4 (= ring slot), source tile, tile in chunk, chunk offset
-  Cursor kcur{0, 0, 0, 0}, vcur{0, 0, 0, 0};
+  // pieces issued so far / 4 (= ring slot), source tile, tile in chunk, physical chunk, element offset of that chunk
+  struct Cursor { int j, t, tt, ci; int64_t off; };
+  const int ci0 = p.chunk_total > 0 ? p.chunk_first : 0;      // the chunks walked are (chunk_first + i) % chunk_total
+  Cursor kcur{0, 0, 0, ci0, (int64_t)ci0 * p.chunk_stride}, vcur = kcur;
   auto advance = [&](Cursor& cu) __attribute__((always_inline)) {
     ++cu.j;
     if (cu.t + 1 < n_tiles) {
       ++cu.t;
-      if (++cu.tt == tiles_per_chunk) { cu.tt = 0; cu.off += p.chunk_stride; }
+      if (++cu.tt == tiles_per_chunk) {
+        cu.tt = 0;
+        if (++cu.ci == p.chunk_total) cu.ci = 0;      // chunk_total = 0 (no wrap) is never reached
+        cu.off = (int64_t)cu.ci * p.chunk_stride;
+      }
     }
   };
   auto uniform = [](const char* q) __attribute__((always_inline)) {      // pin a wave-uniform pointer to scalar registers
@@ -234,6 +243,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   // C operand of a first-k-step MFMA was a dying temporary that hipcc re-used for a ds_read straight after the
   // asm statement - an MFMA reads SrcC over its passes, and hipcc pads SrcC write-after-read only for MFMAs
   // it knows about.)
+  if (STATE == 2) {          // resume: O, m_run, l_run of both blocks from the state the first pass saved
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float* sp = p.state + ((int64_t)bh * p.sq_pad + q0 + 32 * j + l31) * STATE_LD;
+      m_run[j] = sp[HD];
+      l_run[j] = hi == 0 ? sp[HD + 1] : 0.f;       // the two half-lanes' partial sums are added at the end
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) o_write4(j * 4 + d, gq, *reinterpret_cast<const f32x4_t*>(sp + d * 32 + 8 * gq + 4 * hi));
+        asm volatile("" ::: "memory");         // 16 registers of loads in flight at a time, not 128
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[j][r] = -m_run[j];
+    }
+  }
   PIN(negm[0]); PIN(negm[1]);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) { PIN(p0[0][kk]); PIN(p0[1][kk]); PIN(p1[kk]); }
@@ -283,7 +308,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
     const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
     const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
-    const bool first = g == 0;
+    const bool first = g == 0;          // tile 0 always takes the re-base paths (when resuming they only re-base, `init` false)
+    const bool init = first && STATE != 2;
     RowMax rm;
     ExpSumPackT<ABL> es;
 
@@ -316,8 +342,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     float alpha0 = 1.f;
     if (ABL & 2) rm.mx = 0.f;
     if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 0, re-base its scores
-      const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
-      alpha0 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      const float delta = init ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
+      alpha0 = init ? 0.f : __builtin_amdgcn_exp2f(-delta);
       m_run[0] += delta;
       l_run[0] *= alpha0;
 #pragma unroll
@@ -383,8 +409,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     stamp(g, 5);
     if (ABL & 2) rm.mx = 0.f;
     if (first || !__all(rm.mx <= (float)DEFER)) {      // rare: move m_run of block 1
-      const float delta = first ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
-      const float a1 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      const float delta = init ? rm.mx : __builtin_fmaxf(rm.mx, 0.f);
+      const float a1 = init ? 0.f : __builtin_amdgcn_exp2f(-delta);
       m_run[1] += delta;
       l_run[1] *= a1;
 #pragma unroll
@@ -463,8 +489,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   for (int j = 0; j < 2; ++j) {
     float l = l_run[j] - (float)(cnt * p.nchunks) * __builtin_amdgcn_exp2f(-m_run[j]);
     l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
     const int q = q0 + 32 * j + l31;
+    if (STATE == 1) {          // first pass of two: save (O, m, l), every row of the padded block
+      float* sp = p.state + ((int64_t)bh * p.sq_pad + q) * STATE_LD;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4_t*>(sp + d * 32 + 8 * gq + 4 * hi) = o_read4(j * 4 + d, gq);
+      if (hi == 0) { sp[HD] = m_run[j]; sp[HD + 1] = l; }
+      continue;
+    }
+    const float inv = 1.0f / l;
     if (q < p.sq) {
       bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
 #pragma unroll
@@ -484,38 +519,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 }  // namespace
 
 // Main (non-split) grid of the 4x64 kernel: query blocks [0, nblk_main) of every (sequence, head).
-template <int DEFER, int ABL>
+template <int DEFER, int ABL, int STATE>
 static int launch64(const am_attn_args* a, int tiles_per_chunk, int nblk_main, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL, false, STATE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL>), dim3(nblk_main, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
+  hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL, false, STATE>), dim3(nblk_main, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
                      (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr);
   return AM_OK;
 }
 int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
 #ifdef AM_ATTN_ABLATIONS
   switch (a->defer_log2) {     // 3000 + ABL: timing ablations (tools/kernel_bench.py --ablate64)
-    case 3001: return launch64<8, 1>(a, tiles_per_chunk, nblk_main, stream);
-    case 3002: return launch64<8, 2>(a, tiles_per_chunk, nblk_main, stream);
-    case 3004: return launch64<8, 4>(a, tiles_per_chunk, nblk_main, stream);
-    case 3008: return launch64<8, 8>(a, tiles_per_chunk, nblk_main, stream);
-    case 3010: return launch64<8, 10>(a, tiles_per_chunk, nblk_main, stream);
-    case 3014: return launch64<8, 14>(a, tiles_per_chunk, nblk_main, stream);
-    case 3016: return launch64<8, 16>(a, tiles_per_chunk, nblk_main, stream);
-    case 3030: return launch64<8, 30>(a, tiles_per_chunk, nblk_main, stream);
-    case 3032: return launch64<8, 32>(a, tiles_per_chunk, nblk_main, stream);
-    case 3064: return launch64<8, 64>(a, tiles_per_chunk, nblk_main, stream);
-    case 3128: return launch64<8, 128>(a, tiles_per_chunk, nblk_main, stream);
-    case 3132: return launch64<8, 132>(a, tiles_per_chunk, nblk_main, stream);
-    case 3142: return launch64<8, 142>(a, tiles_per_chunk, nblk_main, stream);
+    case 3001: return launch64<8, 1, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3002: return launch64<8, 2, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3004: return launch64<8, 4, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3008: return launch64<8, 8, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3010: return launch64<8, 10, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3014: return launch64<8, 14, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3016: return launch64<8, 16, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3030: return launch64<8, 30, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3032: return launch64<8, 32, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3064: return launch64<8, 64, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3128: return launch64<8, 128, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3132: return launch64<8, 132, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3142: return launch64<8, 142, 0>(a, tiles_per_chunk, nblk_main, stream);
     default: break;
   }
 #endif
-  return defer == 0 ? launch64<0, 0>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0>(a, tiles_per_chunk, nblk_main, stream);
+  if (a->state_mode == 1)
+    return defer == 0 ? launch64<0, 0, 1>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 1>(a, tiles_per_chunk, nblk_main, stream);
+  if (a->state_mode == 2)
+    return defer == 0 ? launch64<0, 0, 2>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 2>(a, tiles_per_chunk, nblk_main, stream);
+  return defer == 0 ? launch64<0, 0, 0>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 0>(a, tiles_per_chunk, nblk_main, stream);
 }
 
 #ifdef AM_ATTN_ABLATIONS

@@ -46,6 +46,9 @@ struct am_model {
   bf16_t *Qb = nullptr, *Kg = nullptr, *Vtg = nullptr;
   bool kv_external = false;
   size_t chunk_elems = 0;
+  size_t chunk_stride = 0;     // elements between consecutive ranks' K (or V^T) chunks
+  float* attn_state = nullptr; // two-pass self-attention: (O, m, l) of every query row after the local K/V shard
+  bool local_done = false;     // am_layer_attn_local ran for the layer in flight
   bf16_t *xb = nullptr, *te0 = nullptr, *te1 = nullptr, *ctxb = nullptr, *kvtmp = nullptr;
   float *tdev = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
 
@@ -248,6 +251,7 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
     const size_t k_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 64) * HD;
     const size_t k_frm = (size_t)BT * m->H * pad_to(m->maxL, 64) * HD;
     m->chunk_elems = k_inf > k_frm ? k_inf : k_frm;
+    m->chunk_stride = m->chunk_elems;
   }
   A_(dev_alloc_t(m, &m->xb, (size_t)BT * m->maxN * Din));
   A_(dev_alloc_t(m, &m->te0, (size_t)BT * C)); A_(dev_alloc_t(m, &m->te1, (size_t)BT * 4 * C));
@@ -310,10 +314,13 @@ extern "C" int am_kv_chunk_elems(am_handle h, size_t* elems) {
   return AM_OK;
 }
 
-extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev) {
+extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev, size_t chunk_stride_elems) {
   AM_CHECK(h && k_dev && vt_dev, "am_bind_kv_buffers: null argument");
-  AM_CHECK(((uintptr_t)k_dev | (uintptr_t)vt_dev) % 16 == 0, "am_bind_kv_buffers: misaligned");
+  AM_CHECK(((uintptr_t)k_dev | (uintptr_t)vt_dev) % 16 == 0 && chunk_stride_elems % 8 == 0, "am_bind_kv_buffers: misaligned");
+  AM_CHECK(chunk_stride_elems == 0 || chunk_stride_elems >= h->chunk_elems, "am_bind_kv_buffers: chunk stride %zu < chunk size %zu",
+           chunk_stride_elems, h->chunk_elems);
   h->Kg = k_dev; h->Vtg = vt_dev; h->kv_external = true;
+  h->chunk_stride = chunk_stride_elems ? chunk_stride_elems : h->chunk_elems;
   return AM_OK;
 }
 
@@ -404,8 +411,8 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   if (h->inflated(i)) {
     hp.seq_len = h->T * L;
     hp.sq_pad = pad_to(hp.seq_len, 256); hp.sk_pad = pad_to(hp.seq_len, 64);
-    hp.out_k = h->Kg + (size_t)h->rank * h->chunk_elems;
-    hp.out_vt = h->Vtg + (size_t)h->rank * h->chunk_elems;
+    hp.out_k = h->Kg + (size_t)h->rank * h->chunk_stride;
+    hp.out_vt = h->Vtg + (size_t)h->rank * h->chunk_stride;
   } else {
     hp.seq_len = L;
     hp.sq_pad = pad_to(L, 256); hp.sk_pad = pad_to(L, 64);
@@ -413,6 +420,39 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   }
   AM_TRY(am_head_post(&hp, st));
   h->pre_done = true;
+  return AM_OK;
+}
+
+// Shared by the one-pass and the two-pass self-attention of an inflated layer.
+static void self_attn_args(am_model* h, am_attn_args* at) {
+  const int L = h->L;
+  at->Q = h->Qb; at->K = h->Kg; at->Vt = h->Vtg; at->O = h->ao;
+  at->heads = h->H; at->ldo = h->C; at->scale = 0.08838834764831845f; at->defer_log2 = h->cfg.attn_defer_log2;
+  at->nseq = h->B; at->sq = h->T * L; at->sq_pad = pad_to(at->sq, 256);
+  at->sk = h->T * L; at->sk_pad = pad_to(at->sk, 64);
+  at->nchunks = h->P; at->chunk_stride = (int64_t)h->chunk_stride;
+}
+
+// Multi-GPU overlap: between am_layer_pre_attn and am_layer_post_attn of an inflated layer, while the all-gather of
+// the other ranks' K / V^T shards is in flight, run the self-attention of the full query blocks against the LOCAL
+// shard only and park the un-normalised (O, m, l).  am_layer_post_attn then resumes over the remote shards.
+// A no-op (AM_OK) when the layer / shapes do not qualify: post_attn falls back to the one-pass attention.
+extern "C" int am_layer_attn_local(am_handle h, int i, void* stream) {
+  AM_CHECK(h, "am_layer_attn_local: null handle");
+  if (!h->in_forward || i != h->next_layer || !h->pre_done)
+    AM_FAIL(AM_ERR_STATE, "am_layer_attn_local: layer %d out of order (next=%d)", i, h->next_layer);
+  h->local_done = false;
+  const int tiles = (h->T * h->L + 63) / 64;
+  const bool product = h->cfg.attn_defer_log2 == 0 || h->cfg.attn_defer_log2 == 8;
+  if (h->P < 2 || !h->inflated(i) || tiles < 16 || !product) return AM_OK;
+  am_attn_args at = {};
+  self_attn_args(h, &at);
+  if (!h->attn_state)
+    AM_TRY(dev_alloc_t(h, &h->attn_state, (size_t)h->maxB * h->H * pad_to((int64_t)h->maxT * h->maxL, 256) * 132));
+  at.rows = 1; at.state_mode = 1; at.state = h->attn_state;
+  at.nchunks = 1; at.chunk_first = h->rank; at.chunk_total = h->P;
+  AM_TRY(am_attention_bf16(&at, stream));
+  h->local_done = true;
   return AM_OK;
 }
 
@@ -429,15 +469,26 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
   am_attn_args at = {};
   at.Q = h->Qb; at.K = h->Kg; at.Vt = h->Vtg; at.O = h->ao;
   at.heads = h->H; at.ldo = C; at.scale = scale; at.defer_log2 = h->cfg.attn_defer_log2;
-  if (h->inflated(i)) {
-    at.nseq = h->B; at.sq = h->T * L; at.sq_pad = pad_to(at.sq, 256);
-    at.sk = h->T * L; at.sk_pad = pad_to(at.sk, 64);
-    at.nchunks = h->P; at.chunk_stride = (int64_t)h->chunk_elems;
+  if (h->inflated(i) && h->local_done) {
+    // second pass: the full blocks resume from the saved state over the P-1 remote shards (rank+1 .. rank-1, wrapping);
+    // the short last block runs one pass over all shards
+    self_attn_args(h, &at);
+    am_attn_args rest = at;
+    at.rows = 1; at.state_mode = 2; at.state = h->attn_state;
+    at.nchunks = h->P - 1; at.chunk_first = (h->rank + 1) % h->P; at.chunk_total = h->P;
+    AM_TRY(am_attention_bf16(&at, st));
+    rest.rows = 2;
+    AM_TRY(am_attention_bf16(&rest, st));
+    h->local_done = false;
   } else {
-    at.nseq = h->B * h->T; at.sq = L; at.sq_pad = pad_to(L, 256);
-    at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
+    if (h->inflated(i)) {
+      self_attn_args(h, &at);
+    } else {
+      at.nseq = h->B * h->T; at.sq = L; at.sq_pad = pad_to(L, 256);
+      at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
+    }
+    AM_TRY(am_attention_bf16(&at, st));
   }
-  AM_TRY(am_attention_bf16(&at, st));
   AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, R, C, C, 0));   // to_out + residual (block.py:137)
   h->hsrc = h->hwork;
   // ---- cross-attention to the frame's own context tokens (block.py:146-149) ----

@@ -94,10 +94,11 @@ class HipEngine:
             if world > 1:
                 n = C.c_size_t()
                 L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
-                k = torch.zeros((world, n.value), dtype=torch.bfloat16, device=self.device)
-                vt = torch.zeros((world, n.value), dtype=torch.bfloat16, device=self.device)
-                L.check(self.lib.am_bind_kv_buffers(self.handle, k.data_ptr(), vt.data_ptr()), "am_bind_kv_buffers")
-                self._kv = (k, vt)
+                # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands
+                kv = torch.zeros((world, 2 * n.value), dtype=torch.bfloat16, device=self.device)
+                L.check(self.lib.am_bind_kv_buffers(self.handle, kv.data_ptr(), kv.data_ptr() + n.value * kv.element_size(),
+                                                    2 * n.value), "am_bind_kv_buffers")
+                self._kv = (kv,)
         self._shape = None
 
     def close(self):
@@ -148,6 +149,11 @@ class HipEngine:
     def layer_pre(self, layer: int) -> None:
         with torch.cuda.device(self.device):
             L.check(self.lib.am_layer_pre_attn(self.handle, layer, self._stream()), "am_layer_pre_attn")
+
+    def layer_attn_local(self, layer: int) -> None:
+        """Optional overlap step: attention against the local K/V shard while the all-gather is in flight."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.am_layer_attn_local(self.handle, layer, self._stream()), "am_layer_attn_local")
 
     def layer_post(self, layer: int) -> None:
         with torch.cuda.device(self.device):

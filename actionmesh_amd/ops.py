@@ -130,12 +130,19 @@ def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, r
     return out_q, out_k, out_vt
 
 
+STATE_LD = 132   # floats per row of a two-pass attention state: O[128], m, l, pad
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: int,
               out: Optional[torch.Tensor] = None, nchunks: int = 1, defer_log2: int = 8,
-              scale: Optional[float] = None) -> torch.Tensor:
+              scale: Optional[float] = None, rows: int = 0, state_mode: int = 0,
+              state: Optional[torch.Tensor] = None, chunk_first: int = 0, chunk_total: int = 0) -> torch.Tensor:
     """softmax(q k^T * scale) v on pre-laid-out operands.
       q (nseq, H, sq_pad, 128); k ([chunks,] nseq, H, sk_pad, 128); vt ([chunks,] nseq, H, 128, sk_pad)
-      -> out (nseq * sq, H * 128)"""
+      -> out (nseq * sq, H * 128)
+    Two-pass form (am_attn_args in include/actionmesh_amd.h): `rows` selects the query blocks (1 = the full blocks,
+    2 = the rest), `state_mode` 1 saves / 2 resumes the (O, m, l) of the full blocks in `state`
+    (nseq * H, sq_pad, STATE_LD) fp32, and the chunks walked are (chunk_first + i) % chunk_total."""
     _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
     nseq, H, sq_pad, _ = q.shape
     sk_pad = k.shape[-2]
@@ -149,6 +156,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
     a.ldo = out.stride(0)
     a.scale = scale if scale is not None else HEAD_DIM ** -0.5
     a.defer_log2 = defer_log2
+    a.rows, a.state_mode, a.chunk_first, a.chunk_total = rows, state_mode, chunk_first, chunk_total
+    if state is not None:
+        _need(state, torch.float32, "state")
+        assert state.numel() >= nseq * H * sq_pad * STATE_LD
+        a.state = state.data_ptr()
     L.check(L.lib().am_attention_bf16(C.byref(a), _stream()), "am_attention_bf16")
     return out
 

@@ -108,25 +108,40 @@ class Engine(Protocol):
     def kv_buffers(self) -> Tuple[torch.Tensor, torch.Tensor]: ...
 
 
-def exchange_kv(kv: Tuple[torch.Tensor, torch.Tensor], plan: FrameShardPlan,
-                group: Optional[dist.ProcessGroup]) -> None:
-    """All-gather the K and V^T shards in place over this rank's frame group.  `kv` tensors are
-    (frame_world, chunk) views; frame shard r has written row r."""
+def exchange_kv(kv: Tuple[torch.Tensor, ...], plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
+                async_op: bool = False) -> list:
+    """All-gather the K / V^T shards in place over this rank's frame group.  `kv` tensors are
+    (frame_world, chunk) views; frame shard r has written row r.  With `async_op` the collectives are only
+    enqueued and their Work handles returned (wait() before reading the other ranks' rows)."""
+    works = []
     for buf in kv:
         assert buf.shape[0] == plan.frame_world and buf.is_contiguous()
         # flat views: accepted by both RCCL and gloo; input aliases its slot of the output
-        dist.all_gather_into_tensor(buf.view(-1), buf[plan.frame_rank].view(-1), group=group)
+        w = dist.all_gather_into_tensor(buf.view(-1), buf[plan.frame_rank].view(-1), group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
 
 
 def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
                     x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
     """One denoiser forward over this rank's (batch rows, frames); returns the local velocity.
-    `group` = the frame group of this rank (ranks that share its CFG branch)."""
+    `group` = the frame group of this rank (ranks that share its CFG branch).
+    Engines that offer `layer_attn_local` (HipEngine) overlap the exchange with the attention of the full query
+    blocks against the local shard: softmax is order-free over keys, so the kernel saves (O, m, l) after the local
+    keys and resumes over the remote ones once they have landed."""
     engine.begin(x_local, t_bt_local)
+    attn_local = getattr(engine, "layer_attn_local", None)
     for i in range(engine.num_layers):
         engine.layer_pre(i)
         if plan.frame_world > 1 and engine.is_inflated(i):
-            exchange_kv(engine.kv_buffers(), plan, group)
+            if attn_local is not None:
+                works = exchange_kv(engine.kv_buffers(), plan, group, async_op=True)
+                attn_local(i)
+                for w in works:
+                    w.wait()
+            else:
+                exchange_kv(engine.kv_buffers(), plan, group)
         engine.layer_post(i)
     return engine.end()
 

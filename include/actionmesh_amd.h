@@ -109,13 +109,20 @@ int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host,
 int am_layer_pre_attn(am_handle h, int layer, void* stream);   /* skip+LN+QKV+qk-norm+RoPE -> local K/V shard */
 int am_layer_post_attn(am_handle h, int layer, void* stream);  /* self-attn .. FFN */
 int am_forward_end(am_handle h, uint16_t* v_out_dev, void* stream);
+/* Optional, multi-GPU: between pre_attn and post_attn of a layer, while the K/V all-gather is in flight, attend to
+ * the LOCAL shard only (two-pass self-attention, am_attn_args.state_mode); post_attn then resumes over the remote
+ * shards.  A no-op when the layer or the shapes do not qualify. */
+int am_layer_attn_local(am_handle h, int layer, void* stream);
 
 /* K / V^T gather buffers for inflated self-attention, laid out
  * [world][B][H][sk_pad][128] (K) and [world][B][H][128][sk_pad] (V^T); this
  * rank writes chunk `rank`.  By default the library owns them; a multi-GPU
- * host binds its own (torch-allocated) buffers so it can all-gather in place. */
+ * host binds its own (torch-allocated) buffers so it can all-gather in place.
+ * `chunk_stride_elems` = distance between consecutive ranks' chunks (0 = elems_per_chunk, i.e. two dense
+ * arrays); 2 * elems_per_chunk with vt_dev = k_dev + elems_per_chunk interleaves [rank][K | V^T] so that ONE
+ * all-gather per layer moves both operands. */
 int am_kv_chunk_elems(am_handle h, size_t* elems_per_chunk);
-int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev);
+int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev, size_t chunk_stride_elems);
 
 /* ClassifierFreeGuidance.aggregate_cfg (guidance.py:95-118) + the Euler flow
  * step and masked write of SchedulerFlow._flow_sample (scheduler.py:238-248):
@@ -192,6 +199,15 @@ typedef struct {
   int32_t nseq, heads, sq, sq_pad, sk, sk_pad, nchunks;
   int64_t chunk_stride;        /* elements between consecutive chunks of K (and of Vt) */
   int32_t ldo; float scale; int32_t defer_log2;
+  /* Two-pass attention over a key stream that arrives in pieces (multi-GPU: the local K/V shard is there before
+   * the all-gather of the others completes).  All zero = one pass over chunks 0 .. nchunks-1.
+   *   chunk_total > 0: the `nchunks` chunks walked are (chunk_first + i) % chunk_total, i = 0 .. nchunks-1;
+   *   rows: 0 = all query blocks, 1 = the full 256-row blocks a long key stream runs on the 4x64 kernel ("main"),
+   *         2 = whatever `rows = 1` leaves out (the short last block);
+   *   state_mode (rows = 1 only): 1 = stop after these chunks and save the un-normalised (O, m, l) of every row
+   *         to `state` ([nseq*heads][sq_pad][132] floats), writing no output; 2 = start from `state`, finish, write O. */
+  int32_t chunk_first, chunk_total, rows, state_mode;
+  float* state;
 } am_attn_args;
 int am_attention_bf16(const am_attn_args* args, void* stream);
 

@@ -255,6 +255,37 @@ def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     assert err < 2e-2, f"attention max abs err {err:.4e} (ref max {ref.abs().max().item():.3f})"
 
 
+@pytest.mark.parametrize("defer", [0, 8])
+@pytest.mark.parametrize("nseq,H,sq,skc,P", [(2, 2, 2320, 1100, 4), (1, 2, 2304, 1024, 2), (1, 1, 2432, 1030, 3)])
+def test_attention_two_pass_matches_one_pass(dev, nseq, H, sq, skc, P, defer):
+    """Multi-GPU overlap path on one GPU: the full query blocks attend to the local key chunk first (state saved),
+    then resume over the other chunks in ring order; the short last block runs one pass.  Every rank's view must
+    reproduce the one-pass result (softmax is order-free over keys) and the fp32 reference."""
+    from actionmesh_amd import ops
+    q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)
+    k = _randn((nseq, H, skc * P, 128), 2, dev).to(torch.bfloat16)
+    v = _randn((nseq, H, skc * P, 128), 3, dev).to(torch.bfloat16)
+    Q, K, Vt, skc_ = _layout(q, k, v, P)
+    assert skc_ == skc
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+    one = ops.attention(Q, K, Vt, sq, skc, nchunks=P, defer_log2=defer).float()
+    assert (one - ref).abs().max().item() < 2e-2
+    state = torch.full((nseq * H, Q.shape[2], ops.STATE_LD), float("nan"), device=dev)
+    for r in range(P):
+        out = torch.full((nseq * sq, H * 128), 768.0, dtype=torch.bfloat16, device=dev)
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=1, defer_log2=defer, rows=1, state_mode=1, state=state,
+                      chunk_first=r, chunk_total=P)
+        assert (out.float() == 768.0).all(), "the first pass must not write the output"
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=P - 1, defer_log2=defer, rows=1, state_mode=2, state=state,
+                      chunk_first=(r + 1) % P, chunk_total=P)
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=P, defer_log2=defer, rows=2)
+        torch.cuda.synchronize()
+        o = out.float()
+        assert not (o == 768.0).any(), f"rank {r}: rows left unwritten"
+        assert (o - ref).abs().max().item() < 2e-2, f"rank {r} vs fp32 reference"
+        assert (o - one).abs().max().item() < 1.6e-2, f"rank {r} vs one pass"
+
+
 def test_attention_forced_rescale_branch(dev):
     """A key that dominates late in the stream forces the online-softmax rescale branch with the
     deferred-rescale threshold active (cdna guide section 5.4 rule 26); threshold 0 and 8 must agree."""

@@ -100,6 +100,26 @@ class OracleEngine:
         return self.P.linear(h, sd["proj_out.weight"], sd["proj_out.bias"]).reshape(self.B, self.T, self.N, -1)
 
 
+class OverlapOracleEngine(OracleEngine):
+    """Stand-in that also offers HipEngine's optional overlap hook: sharded_forward must then enqueue the all-gather
+    asynchronously, call the hook once per exchanged layer, and wait before layer_post."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.local_calls, self.pending = [], None
+
+    def layer_attn_local(self, i):
+        assert self.is_inflated(i) and self.plan.frame_world > 1
+        self.local_calls.append(i)
+        self.pending = i
+
+    def layer_post(self, i):
+        if self.is_inflated(i) and self.plan.frame_world > 1:
+            assert self.pending == i, "layer_attn_local must run between layer_pre and layer_post"
+        self.pending = None
+        super().layer_post(i)
+
+
 def _inputs():
     g = torch.Generator().manual_seed(5)
     B, T, N, S = 2, 4, 20, 7
@@ -111,7 +131,7 @@ def _inputs():
     return x, ctx, fs, mask, t
 
 
-def _worker(rank, world, port, q, cfg_groups=1):
+def _worker(rank, world, port, q, cfg_groups=1, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -127,9 +147,11 @@ def _worker(rank, world, port, q, cfg_groups=1):
         cos, sin = rope_tables_host(fs, 128)                         # from the FULL window's framesteps
         cos = plan.slice_local(cos.repeat_interleave(2, -1).view(B, T, -1)).reshape(-1, 128)
         sin = plan.slice_local(sin.repeat_interleave(2, -1).view(B, T, -1)).reshape(-1, 128)
-        eng = OracleEngine(sd, cfg, plan, plan.slice_local(ctx), cos, sin, plan.batch_local, N)
+        eng = (OverlapOracleEngine if overlap else OracleEngine)(sd, cfg, plan, plan.slice_local(ctx), cos, sin, plan.batch_local, N)
         t_local = plan.local_times(masked_time(t.tolist(), mask, B, T))
         v_local = sharded_forward(eng, plan, groups[plan.cfg_rank], plan.slice_local(x), t_local)
+        if overlap and plan.frame_world > 1:
+            assert eng.local_calls == [i for i in range(cfg.num_layers) if eng.is_inflated(i)]
         v = gather_frames(v_local, plan, None)
         if rank == 0:
             q.put(v)
@@ -137,11 +159,11 @@ def _worker(rank, world, port, q, cfg_groups=1):
         dist.destroy_process_group()
 
 
-def _run_world(world, cfg_groups):
+def _run_world(world, cfg_groups, overlap=False):
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
-    port = 29400 + (os.getpid() * 7 + world * 13 + cfg_groups) % 500
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cfg_groups)) for r in range(world)]
+    port = 29400 + (os.getpid() * 7 + world * 13 + cfg_groups + 100 * overlap) % 500
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, cfg_groups, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     v = q.get(timeout=240)
@@ -165,6 +187,13 @@ def test_cfg_parallel_times_frame_shard_equals_unsharded_oracle(world, cfg_group
 @pytest.mark.timeout(300)
 def test_world2_sharded_forward_equals_unsharded_oracle():
     _run_world(2, 1)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,cfg_groups", [(2, 1), (4, 2)])
+def test_async_exchange_with_local_attention_hook(world, cfg_groups):
+    """Engines offering layer_attn_local get the overlapped protocol: async all-gather, hook, wait, post."""
+    _run_world(world, cfg_groups, overlap=True)
 
 
 def test_world1_driver_is_identity_plan():

@@ -183,7 +183,9 @@ def main():
     torch.cuda.set_device(dev)
     group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # lazy communicator creation on the current device (no device_id: eager init would create the CFG-branch
+        # sub-groups by communicator split, which not every RCCL build supports)
+        dist.init_process_group("nccl")
         group = dist.group.WORLD
 
     T, N, C, H, NL, S, Dc, Din = SHAPES[args.shape]
@@ -206,7 +208,7 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
     loop = sched._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
@@ -248,7 +250,7 @@ def main():
         torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -36,6 +36,9 @@ SHAPES = {
     "headline": (16, 4096, 1024, 8, 21, 257, 1024, 64),     # "16f x 4096tok x 1024-dim"
     "nominal": (16, 2048, 2048, 16, 21, 257, 1024, 64),     # the shipped model (actionmesh.yaml:33-43)
     "small": (4, 512, 256, 2, 5, 17, 64, 64),               # plumbing check
+    # BASELINE.json configs[4] in bf16: 64 frames x 8192 tokens (T*L = 524 352-token attention, 64x the headline's
+    # attention flops: ~45 s per step on one GPU - meant for 8 GPUs; fits one MI355X: ~40 GB of activations)
+    "long64": (64, 8192, 1024, 8, 21, 257, 1024, 64),
 }
 
 
@@ -230,7 +233,7 @@ def main():
     step_flops = model._engine.step_flops(2, T, N, S)
     steps_per_s = args.steps / elapsed
     result = {
-        "metric": "denoise-steps/sec (16f x 4096tok)", "value": round(steps_per_s, 4),
+        "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
         "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -320,3 +320,45 @@ def test_overlap_path_emulated_on_one_gpu(dev, world):
     # different key orders round P to bf16 against different running maxima: both sharded variants sit at the same
     # distance from the unsharded run
     assert r < 1e-2 and r1 < 1e-2 and r01 < 1e-2
+
+
+def test_autoregressive_windows_match_oracle(dev):
+    """SURVEY 8(f) N3 on the HIP path: 7 frames, window 4, slide 3, anchor in the middle - three dependent windows
+    (each conditions on the previous ones' output through the device-resident LatentBank) against the CPU oracle's
+    restatement of pipeline.py:247-314/469-506 with the same CPU-drawn noise.  Tolerance: the per-step latent
+    tolerance of the sampler (2e-2 rel-L2 vs fp32), with head-room for the error carried through the conditioning
+    frames of later windows."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+    from actionmesh_amd import windows as W
+    from oracle import denoiser_oracle as O
+    from oracle import windows_oracle as WO
+    hp = CASES["tiny_inflated"]
+    cfg = O.OracleConfig(**hp)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    model = HipDenoiser(num_tokens_nominal=48, temporal_context_size=4, **hp)
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    T, N, D, S, steps = 7, 48, 64, 9, 3
+    g = torch.Generator().manual_seed(21)
+    ts = torch.arange(T, dtype=torch.float32)
+    context = torch.randn((T, S, 64), generator=g)
+    anchor = torch.randn((1, N, D), generator=g)
+    sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+
+    bank = W.LatentBank(empty_dims=(N, D), device=str(dev))
+    bank.update(ts[2:3], anchor)
+    W.generate_3d_latents(model, sched, cfgd, ts, context.to(dev), bank, anchor_idx=2, window=4, slide=3,
+                          latent_shape=(N, D), seed=44, device=dev, noise_device="cpu")
+    ref = WO.ListLatentBank((N, D))
+    ref.update(ts[2:3], anchor)
+    WO.generate_3d_latents(sd, cfg, ts, context, ref, 2, 4, 3, (N, D), steps, seed=44)
+    torch.cuda.synchronize()
+
+    lat, t_sorted = bank.get_ordered()
+    lat_ref, t_ref = ref.get_ordered()
+    assert t_sorted.cpu().tolist() == t_ref.tolist() == list(range(T))
+    assert torch.equal(lat[2].cpu(), anchor[0]), "the anchor latent is conditioning only"
+    per_frame = [rel(lat[i].cpu(), lat_ref[i]) for i in range(T) if i != 2]
+    print("AR windows: per-frame rel-L2 vs fp32 oracle", [f"{r:.2e}" for r in per_frame])
+    assert max(per_frame) < 3e-2

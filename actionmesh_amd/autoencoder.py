@@ -1,0 +1,189 @@
+"""Stage II on the Stage-I kernels: host-side mirror of the reference's
+`ActionMeshAutoencoder` (actionmesh/model/temporal_autoencoder.py:80-267) - same constructor fields, the reference
+state-dict keys, `forward(latent, framestep, source_alpha, target_alphas, query, step_callback)` -> displacement.
+
+The reference is Python; so is this orchestration.  Every arithmetic step is a call through the C-ABI
+(`am_gemm_bf16`, `am_layernorm_bf16`, `am_head_post`, `am_attention_bf16`, `am_point_embed`, `am_displacement`);
+torch only owns device memory and moves rows around.  There is no CPU / torch fallback.
+
+What the reference does per target timestep (temporal_autoencoder.py:244-265):
+  tokens = [T*N projected latents | T alpha tokens]  ->  16 x FlowMatchingBlock(self-attention with temporal RoPE, FF)
+  ->  kv cache  ->  one FlowMatchingBlock(cross-attention of the V embedded query points to the kv cache, FF)
+  ->  LayerNorm, Linear(width -> 3), * -1;   finally 2 sigmoid - 1.
+MI355X-first layout: self-attention is permutation-equivariant and the RoPE angle depends on the frame only, so the
+sequence is kept frame-major exactly like Stage I's (`[alpha token | N latent tokens]` per frame, L = N + 1 rows):
+the Stage-I kernels apply unchanged (head_post without qk-norm, 4x64 attention over the T*L tokens), and the
+cross-attention does not care about key order.  The rows of the projected latents are written once and re-used by all
+targets; only the T alpha rows change between targets.
+Precision: bf16 storage / fp32 accumulation like Stage I (the reference runs the self-attention stack under cuda
+autocast and the query side in fp32); tolerance stated in tests/test_autoencoder_gpu.py.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import lib
+from .denoiser import rope_tables_host
+
+
+class HipAutoencoder:
+    def __init__(self, temporal_context_size: int = 16, in_channels: int = 3, in_extra_channels: int = 3, out_dim: int = 3,
+                 latent_channels: int = 64, width: int = 1024, num_layers: int = 16, num_attention_heads: int = 8,
+                 embed_frequency: int = 8, embed_include_pi: bool = False, prediction_mode: str = "direct",
+                 verbose: bool = False, **_ignored):
+        if width % num_attention_heads or width // num_attention_heads != ops.HEAD_DIM:
+            raise ValueError("HipAutoencoder: the kernels are built for head_dim 128 (width = 128 * heads)")
+        if latent_channels % 64 or width % 64:
+            raise ValueError("HipAutoencoder: latent_channels and width must be multiples of 64")
+        self.temporal_context_size = temporal_context_size
+        self.in_channels, self.in_extra_channels, self.out_dim = in_channels, in_extra_channels, out_dim
+        self.latent_channels, self.width, self.num_layers, self.heads = latent_channels, width, num_layers, num_attention_heads
+        self.embed_frequency, self.embed_include_pi = embed_frequency, embed_include_pi
+        self.prediction_mode, self.verbose = prediction_mode, verbose
+        self.query_dim = in_channels * (2 * embed_frequency + 1) + in_extra_channels
+        self.query_pad = ops.round_up(self.query_dim, 64)
+        self.device = torch.device("cpu")
+        self._sd: Optional[Dict[str, torch.Tensor]] = None
+        self._w: Dict[str, torch.Tensor] = {}
+        lib()      # fail loudly here if libactionmesh_amd.so is missing
+
+    # ---- nn.Module-like surface ---------------------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self._sd is not None:
+            self._upload()
+        return self
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        need = {f"blocks.{self.num_layers}.x_attn.to_q.weight", "post_quant.weight", "proj_query.weight", "proj_out.weight"}
+        missing = [k for k in need if k not in sd]
+        if missing:
+            raise KeyError(f"HipAutoencoder.load_state_dict: missing {missing}")
+        self._sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+        if self.device.type == "cuda":
+            self._upload()
+        return self
+
+    def _upload(self) -> None:
+        sd, dev, C = self._sd, self.device, self.width
+        bf = lambda t: t.to(dev, torch.bfloat16).contiguous()
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        w: Dict[str, torch.Tensor] = {}
+        for i in range(self.num_layers):
+            p = f"blocks.{i}."
+            # row-concatenated [to_q; to_k; to_v]: the reference splits the CONCATENATED projection per head
+            # (attention_processor.py:105-110), which am_head_post reproduces on the (rows, 3C) GEMM output
+            w[p + "qkv"] = bf(torch.cat([sd[p + f"s_attn.{n}.weight"] for n in ("to_q", "to_k", "to_v")], 0))
+            w[p + "o"], w[p + "o_b"] = bf(sd[p + "s_attn.to_out.0.weight"]), f32(sd[p + "s_attn.to_out.0.bias"])
+            w[p + "ff1"], w[p + "ff1_b"] = bf(sd[p + "ff.net.0.proj.weight"]), f32(sd[p + "ff.net.0.proj.bias"])
+            w[p + "ff2"], w[p + "ff2_b"] = bf(sd[p + "ff.net.2.weight"]), f32(sd[p + "ff.net.2.bias"])
+            for n in ("norm_s_attn", "norm_ff"):
+                w[p + n + ".w"], w[p + n + ".b"] = f32(sd[p + n + ".weight"]), f32(sd[p + n + ".bias"])
+        p = f"blocks.{self.num_layers}."
+        w[p + "q"] = bf(sd[p + "x_attn.to_q.weight"])
+        w[p + "kv"] = bf(torch.cat([sd[p + "x_attn.to_k.weight"], sd[p + "x_attn.to_v.weight"]], 0))
+        w[p + "o"], w[p + "o_b"] = bf(sd[p + "x_attn.to_out.0.weight"]), f32(sd[p + "x_attn.to_out.0.bias"])
+        w[p + "ff1"], w[p + "ff1_b"] = bf(sd[p + "ff.net.0.proj.weight"]), f32(sd[p + "ff.net.0.proj.bias"])
+        w[p + "ff2"], w[p + "ff2_b"] = bf(sd[p + "ff.net.2.weight"]), f32(sd[p + "ff.net.2.bias"])
+        for n, key in (("norm_x_attn", "norm_x_attn"), ("norm_cross", "x_attn.norm_cross"), ("norm_ff", "norm_ff")):
+            w[p + n + ".w"], w[p + n + ".b"] = f32(sd[p + key + ".weight"]), f32(sd[p + key + ".bias"])
+        pq = torch.zeros((C, self.query_pad))
+        pq[:, : self.query_dim] = sd["proj_query.weight"]                       # K padded to a multiple of 64
+        w["proj_query"], w["proj_query_b"] = bf(pq), f32(sd["proj_query.bias"])
+        po, pob = torch.zeros((8, C)), torch.zeros(8)                           # N padded to a multiple of 8
+        po[: self.out_dim], pob[: self.out_dim] = sd["proj_out.weight"], sd["proj_out.bias"]
+        w["proj_out"], w["proj_out_b"] = bf(po), f32(pob)
+        w["norm_out.w"], w["norm_out.b"] = f32(sd["norm_out.weight"]), f32(sd["norm_out.bias"])
+        w["post_quant"], w["post_quant_b"] = bf(sd["post_quant.weight"]), f32(sd["post_quant.bias"])
+        self._w = w
+
+    # ---- building blocks ------------------------------------------------------------------------------------
+    def _ff(self, p: str, h: torch.Tensor) -> torch.Tensor:
+        w = self._w
+        z = ops.layernorm(h, w[p + "norm_ff.w"], w[p + "norm_ff.b"])
+        f = ops.gemm(z, w[p + "ff1"], bias=w[p + "ff1_b"], gelu=True)
+        return ops.gemm(f, w[p + "ff2"], bias=w[p + "ff2_b"], residual=h)
+
+    def _self_block(self, i: int, h: torch.Tensor, B: int, T: int, L: int, rope) -> torch.Tensor:
+        w, p = self._w, f"blocks.{i}."
+        z = ops.layernorm(h, w[p + "norm_s_attn.w"], w[p + "norm_s_attn.b"])
+        qkv = ops.gemm(z, w[p + "qkv"])
+        Q, K, Vt = ops.head_post(qkv, self.heads, (0, 1, 2), T * L, L, rope=rope)        # no qk-norm, temporal RoPE
+        a = ops.attention(Q, K, Vt, T * L, T * L)
+        h = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"], residual=h)
+        return self._ff(p, h)
+
+    def _cross_block(self, qh: torch.Tensor, kv_cache: torch.Tensor, B: int, V: int, S: int) -> torch.Tensor:
+        w, p = self._w, f"blocks.{self.num_layers}."
+        e = ops.layernorm(kv_cache, w[p + "norm_cross.w"], w[p + "norm_cross.b"])         # nn.LayerNorm, eps 1e-5
+        kv = ops.gemm(e, w[p + "kv"])
+        _, K, Vt = ops.head_post(kv, self.heads, (1, 2), S, S)
+        z = ops.layernorm(qh, w[p + "norm_x_attn.w"], w[p + "norm_x_attn.b"])
+        q = ops.gemm(z, w[p + "q"])
+        Q, _, _ = ops.head_post(q, self.heads, (0,), V, V)
+        a = ops.attention(Q, K, Vt, V, S)
+        h = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"], residual=qh)
+        return self._ff(p, h)
+
+    # ---- forward (temporal_autoencoder.py:160-267) --------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, latent: torch.Tensor, framestep: torch.Tensor, source_alpha: torch.Tensor,
+                target_alphas: torch.Tensor, query: torch.Tensor,
+                step_callback: Optional[Callable[[int, int], None]] = None) -> torch.Tensor:
+        if self.device.type != "cuda" or not self._w:
+            raise RuntimeError("HipAutoencoder: load_state_dict(...) and .to('cuda:N') first (there is no CPU path)")
+        assert target_alphas.ndim == 2 and source_alpha.ndim == 1
+        dev, C, w = self.device, self.width, self._w
+        B, T, N, D = latent.shape
+        T_out, V, L = target_alphas.shape[1], query.shape[1], N + 1
+        with torch.cuda.device(dev):
+            # projected latents into the frame-major residual layout, once (rows f*L + 1 + n; row f*L is the alpha token)
+            base = torch.zeros((B * T * L, C), dtype=torch.bfloat16, device=dev)
+            ops.gemm(ops.f32_to_bf16(latent.to(dev, torch.float32).reshape(B * T * N, D).contiguous()), w["post_quant"],
+                     bias=w["post_quant_b"], out=base, c_map=(N, L, 1), M=B * T * N)
+            cos, sin = rope_tables_host(framestep)                                # scale_timestep(center) (:198-209)
+            rope = (cos.to(dev), sin.to(dev))
+            # alpha tokens: TimestepEmbedder(source, target) = [cos | sin](source) | [cos | sin](target), width/2 each (:232-235)
+            half = C // 4
+            freqs = torch.exp(-math.log(10_000) * torch.arange(half, dtype=torch.float32) / half)
+            src = source_alpha.detach().float().cpu()[:, None].expand_as(target_alphas)
+            emb = []
+            for t in (src, target_alphas.detach().float().cpu()):
+                arg = t[..., None] * freqs
+                emb += [torch.cos(arg), torch.sin(arg)]
+            alpha = torch.cat(emb, -1).to(dev, torch.bfloat16)                    # (B, T_out, C)
+            # query side, once: embed + proj_query
+            qe = ops.point_embed(query.to(dev, torch.float32).reshape(B * V, -1).contiguous(), self.in_channels,
+                                 self.in_extra_channels, self.embed_frequency, self.embed_include_pi, self.query_pad)
+            qh = ops.gemm(qe, w["proj_query"], bias=w["proj_query_b"])
+            out = torch.empty((B, T_out, V, self.out_dim), dtype=torch.float32, device=dev)
+            for i in range(T_out):
+                if step_callback is not None:
+                    step_callback(i + 1, T_out)
+                h = base.clone()
+                h.view(B, T, L, C)[:, :, 0] = alpha[:, i][:, None]
+                for li in range(self.num_layers):
+                    h = self._self_block(li, h, B, T, L, rope)
+                hq = self._cross_block(qh, h, B, V, T * L)
+                z = ops.layernorm(hq, w["norm_out.w"], w["norm_out.b"])
+                lg = ops.gemm(z, w["proj_out"], bias=w["proj_out_b"])            # (B*V, 8): 3 logits + padding
+                for b in range(B):
+                    ops.displacement(lg[b * V:(b + 1) * V], self.out_dim, out[b, i])
+            return out
+
+    __call__ = forward
+
+    def apply_displacement(self, vertex: torch.Tensor, displacement: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """temporal_autoencoder.py:118-141."""
+        if self.prediction_mode == "direct":
+            return torch.clamp(displacement, min=-1.0 * scale, max=1.0 * scale)
+        if self.prediction_mode == "residual":
+            return torch.clamp(vertex[:, None] + displacement, min=-1.0 * scale, max=1.0 * scale)
+        raise ValueError(f"Invalid prediction_mode: {self.prediction_mode}")

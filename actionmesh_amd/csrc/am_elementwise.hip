@@ -99,6 +99,57 @@ extern "C" int am_timestep_sinusoid(const float* t_dev, uint16_t* out, int rows,
   return AM_OK;
 }
 
+// ---- Stage II (temporal_autoencoder.py) input / output featurisation -------------------------------------------
+// FrequencyPositionalEmbedding (embeddings.py:14-52, logspace, include_input) + the extra channels (normals):
+//   out[row] = [x (3) | sin(x_c f_j), c-major (3F) | cos(x_c f_j) (3F) | extra | 0-pad], f_j = 2^j (* pi)
+__global__ void point_embed_kernel(const float* __restrict__ q, int ld_in, int64_t rows, int in_ch, int extra, int nfreq,
+                                   float fscale, bf16_t* __restrict__ out, int ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld_out) return;
+  const int64_t row = i / ld_out;
+  const int c = (int)(i - row * ld_out);
+  const float* x = q + row * ld_in;
+  const int nf = in_ch * nfreq;
+  float v = 0.f;
+  if (c < in_ch) v = x[c];
+  else if (c < in_ch + 2 * nf) {
+    const int e = (c - in_ch) % nf;
+    const float a = x[e / nfreq] * (fscale * (float)(1 << (e % nfreq)));
+    v = c < in_ch + nf ? sinf(a) : cosf(a);
+  } else if (c < in_ch + 2 * nf + extra) v = x[in_ch + (c - in_ch - 2 * nf)];
+  out[i] = f2bf(v);
+}
+// temporal_autoencoder.py:156-157, 267: logits * -1, then 2 * sigmoid - 1
+__global__ void displacement_kernel(const bf16_t* __restrict__ logits, int ld, int64_t rows, int out_dim, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * out_dim) return;
+  const int64_t row = i / out_dim;
+  const float x = -bf2f(logits[row * ld + (i - row * out_dim)]);
+  out[i] = 2.0f / (1.0f + __expf(-x)) - 1.0f;
+}
+
+extern "C" int am_point_embed(const float* q_dev, int ld_in, int64_t rows, int in_channels, int extra_channels, int num_freqs,
+                              int include_pi, uint16_t* out, int ld_out, void* stream) {
+  AM_CHECK(q_dev && out && rows > 0, "am_point_embed: bad args");
+  AM_CHECK(in_channels > 0 && extra_channels >= 0 && num_freqs > 0 && num_freqs < 24 && ld_in >= in_channels + extra_channels,
+           "am_point_embed: bad channel counts");
+  AM_CHECK(ld_out >= in_channels * (2 * num_freqs + 1) + extra_channels, "am_point_embed: ld_out=%d too small", ld_out);
+  const int64_t n = rows * ld_out;
+  hipLaunchKernelGGL(point_embed_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, q_dev, ld_in,
+                     rows, in_channels, extra_channels, num_freqs, include_pi ? 3.14159265358979323846f : 1.0f, out, ld_out);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_displacement(const uint16_t* logits, int ld, int64_t rows, int out_dim, float* out, void* stream) {
+  AM_CHECK(logits && out && rows > 0 && out_dim > 0 && ld >= out_dim, "am_displacement: bad args");
+  const int64_t n = rows * out_dim;
+  hipLaunchKernelGGL(displacement_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                     rows, out_dim, out);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 extern "C" int am_flow_step(const uint16_t* v_dev, float* latents_dev, int n_branches, const float* scales_host,
                             float dt, int is_additive, const uint8_t* unobserved_host, int T_local, int N, int Din,
                             void* stream) {

@@ -180,6 +180,25 @@ def timestep_sinusoid(t: torch.Tensor, width: int) -> torch.Tensor:
     return y
 
 
+def point_embed(query: torch.Tensor, in_channels: int, extra_channels: int, num_freqs: int, include_pi: bool,
+                ld_out: int = 64) -> torch.Tensor:
+    """query (rows, >= in+extra) fp32 -> bf16 (rows, ld_out): FrequencyPositionalEmbedding + extras, zero padded."""
+    _need(query, torch.float32, "query")
+    rows = query.shape[0]
+    out = torch.empty((rows, ld_out), dtype=torch.bfloat16, device=query.device)
+    L.check(L.lib().am_point_embed(query.data_ptr(), query.stride(0), rows, in_channels, extra_channels, num_freqs,
+                                   int(include_pi), out.data_ptr(), ld_out, _stream()), "am_point_embed")
+    return out
+
+
+def displacement(logits: torch.Tensor, out_dim: int, out: torch.Tensor) -> torch.Tensor:
+    """out (rows, out_dim) fp32 = 2 sigmoid(-logits[:, :out_dim]) - 1."""
+    _need(logits, torch.bfloat16, "logits"); _need(out, torch.float32, "out")
+    L.check(L.lib().am_displacement(logits.data_ptr(), logits.stride(0), logits.shape[0], out_dim, out.data_ptr(), _stream()),
+            "am_displacement")
+    return out
+
+
 def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], dt: float,
               is_additive: bool, unobserved: Optional[Sequence[bool]]) -> None:
     """In place: latents (T, N, D) fp32 += sign * bf16(dt * cfg(v)); v (n_branches, T, N, D) bf16."""

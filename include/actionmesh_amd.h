@@ -217,6 +217,14 @@ int am_bf16_to_f32(const uint16_t* x, float* y, size_t n, void* stream);
 /* diffusers Timesteps(flip_sin_to_cos=False, shift=0): [sin(t f) | cos(t f)] -> bf16 (rows, C) */
 int am_timestep_sinusoid(const float* t_dev, uint16_t* out, int rows, int C, void* stream);
 
+/* Stage II (ActionMeshAutoencoder, temporal_autoencoder.py) featurisation around the kernels above:
+ *   am_point_embed: FrequencyPositionalEmbedding (embeddings.py:14-52) of query (rows, ld_in) fp32 = [xyz | extra] ->
+ *                   bf16 (rows, ld_out) = [x | sin(x f) | cos(x f) | extra | 0 pad], f_j = 2^j (* pi if include_pi)
+ *   am_displacement: out (rows, out_dim) fp32 = 2 sigmoid(-logits) - 1   (temporal_autoencoder.py:156-157, 267) */
+int am_point_embed(const float* q_dev, int ld_in, int64_t rows, int in_channels, int extra_channels, int num_freqs,
+                   int include_pi, uint16_t* out, int ld_out, void* stream);
+int am_displacement(const uint16_t* logits, int ld, int64_t rows, int out_dim, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,21 @@ class HipAutoencoder:
         lib()      # fail loudly here if libactionmesh_amd.so is missing
 
     # ---- nn.Module-like surface ---------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path: str, **kwargs) -> "HipAutoencoder":
+        """Reads the PyTorchModelHubMixin layout the reference uses (pipeline.py:186-199):
+        <path>/config.json + <path>/model.safetensors."""
+        import json
+        import os
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        fields = ("temporal_context_size", "in_channels", "in_extra_channels", "out_dim", "latent_channels", "width",
+                  "num_layers", "num_attention_heads", "embed_frequency", "embed_include_pi", "prediction_mode")
+        model = cls(**{k: cfg[k] for k in fields if k in cfg}, **kwargs)
+        model.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
+        return model
+
     def eval(self):
         return self
 

@@ -45,6 +45,21 @@ def test_oracle_embeddings_known_answers():
     assert torch.allclose(p[0], torch.tensor(want, dtype=torch.float32), atol=1e-6)
 
 
+def test_from_pretrained_reads_the_reference_layout(tmp_path, golden_dir):
+    """config.json + model.safetensors as ActionMeshAutoencoder.from_pretrained writes them (no GPU needed to load)."""
+    import json
+    from safetensors.torch import save_file
+    from actionmesh_amd.autoencoder import HipAutoencoder
+    cfg, sd, _ = _case(golden_dir)
+    (tmp_path / "config.json").write_text(json.dumps(dict(width=cfg.width, num_layers=cfg.num_layers,
+                                                          num_attention_heads=cfg.num_attention_heads, verbose=False)))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "model.safetensors"))
+    m = HipAutoencoder.from_pretrained(str(tmp_path))
+    assert (m.width, m.num_layers, m.heads, m.query_dim, m.query_pad) == (cfg.width, cfg.num_layers, 2, 54, 64)
+    with pytest.raises(RuntimeError):      # no CPU path
+        m.forward(torch.zeros(1, 2, 4, 64), torch.zeros(1, 2), torch.zeros(1), torch.zeros(1, 1), torch.zeros(1, 3, 6))
+
+
 @pytest.mark.gpu
 def test_hip_autoencoder_matches_reference_fixture_and_oracle(golden_dir):
     if not torch.cuda.is_available():

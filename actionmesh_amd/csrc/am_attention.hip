@@ -3,6 +3,11 @@
 // attention_processor.py:133-139 for both the inflated self-attention
 // (seq = T*L, 68-99 % of the step's flops) and the per-frame cross-attention.
 //
+// This file: the entry point am_attention_bf16 (dispatch, split tail, two-pass row selection) and the 8-wave kernel.
+// Long key streams (>= 16 tiles: the inflated self-attention) run their full 256-row query blocks on the 4-wave x
+// 64-row kernel of am_attention64.hip, which shares every layout described here; the 8-wave kernel below serves
+// short key streams (cross-attention), the short last query block (split over the key range) and A/B comparisons.
+//
 // Work decomposition: one workgroup = 8 waves = 256 query rows of one
 // (sequence, head); each wave owns 32 query rows.  Keys/values stream through
 // LDS in super-tiles of 128 keys (two 64-key sub-tiles), double-buffered

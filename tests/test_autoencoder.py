@@ -105,3 +105,33 @@ def test_point_embed_and_displacement_kernels():
     ops.displacement(lg.to(dev), 3, out)
     want = 2 * torch.sigmoid(-lg.float()[:, :3]) - 1
     assert float((out.cpu() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_autoencoder_properties_at_model_width():
+    """Size-independent properties at the shipped width (1024 / 8 heads; 2 + 1 blocks, 8 frames x 1023 tokens so that
+    the self-attention runs on the long-key-stream kernel): (a) outputs in [-1, 1] and finite; (b) permuting the query
+    vertices permutes the displacements (each vertex attends independently); (c) source == target with the same
+    weights is deterministic across calls; (d) extra padded query channels do not leak (first 3 output dims only)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from actionmesh_amd.autoencoder import HipAutoencoder
+    dev = torch.device("cuda:0")
+    cfg = AO.AEConfig(width=1024, num_layers=2, num_attention_heads=8)
+    sd = AO.synthetic_state_dict(cfg, seed=1)
+    m = HipAutoencoder(width=1024, num_layers=2, num_attention_heads=8)
+    m.load_state_dict(sd)
+    m.to(dev)
+    g = torch.Generator().manual_seed(5)
+    B, T, N, V = 1, 8, 1023, 1500
+    latent = torch.randn((B, T, N, 64), generator=g)
+    fs = torch.arange(T, dtype=torch.float32)[None]
+    query = torch.cat([torch.rand((B, V, 3), generator=g) * 2 - 1, torch.randn((B, V, 3), generator=g)], -1)
+    src, tgt = torch.tensor([0.5]), torch.tensor([[0.0, 0.5]])
+    d = m(latent.to(dev), fs, src, tgt, query.to(dev))
+    assert d.shape == (B, 2, V, 3) and bool(torch.isfinite(d).all()) and float(d.abs().max()) <= 1.0
+    perm = torch.randperm(V, generator=g)
+    dp = m(latent.to(dev), fs, src, tgt, query[:, perm].to(dev))
+    assert float((dp - d[:, :, perm.to(dev)]).abs().max()) < 2e-2      # bf16 noise only (different tile membership)
+    d2 = m(latent.to(dev), fs, src, tgt, query.to(dev))
+    assert torch.equal(d, d2), "same inputs, same bits"

@@ -14,12 +14,19 @@
 //     are initialised while its previous softmax may still move m_run; that offset is carried as a
 //     pending correction (`pend`), applied in the (rare) tile after a rescale;
 //   * K/V^T tiles (64 keys) live in a 4-deep LDS ring (128 KiB): in iteration g the MFMAs read V^T(g-1) and
-//     K(g+1), tile g+2 is in flight (LDS-DMA), one barrier per tile;
+//     K(g+1); K is fetched three tiles ahead and V^T two (LDS-DMA pieces issued one per MFMA pair inside the two
+//     light phases, source = scalar base + 32-bit lane offset), one barrier per tile with a counted
+//     s_waitcnt vmcnt(8); fragments sit in explicit rotating register sets with HOLD() keep-alives;
 //   * the padded keys of a chunk's partial last tile score exactly 0 and their exp2(-m) is removed from the
-//     row sums once, after the loop (rescales multiply it like every other term).
+//     row sums once, after the loop (rescales multiply it like every other term);
+//   * O (128) and the pre-scaled Q (64) live in AccVGPRs a[0:191], named literally in the inline asm of
+//     am_attention64_asm.inc (P.V runs as AGPR-form MFMAs, QK^T takes its B operand from the accumulator file);
+//   * two-pass form for the multi-GPU overlap (STATE): save (O, m, l) after the local key chunk, resume over
+//     the remote chunks in ring order (am_attn_args.state_mode / chunk_first / chunk_total).
 // Compiled with -fno-slp-vectorize (v_pk_*_f32 beside MFMAs costs more than two scalar ops on gfx950) and
-// IEEE mode off for this file, so fmaxf chains become v_max3_f32 without canonicalising v_max's and hipcc
-// (not hand-written asm) owns every MFMA -> VALU hazard.
+// IEEE mode off for this file, so fmaxf chains become v_max3_f32 without canonicalising v_max's; hipcc owns the
+// MFMA -> VALU hazards of its own instructions, the asm statements carry theirs (DESIGN.md 4.1 lists the three
+// that bit: SrcC write-after-read, in-flight results at loop exit, operand registers re-used too early).
 #include "am_common.h"
 
 namespace {

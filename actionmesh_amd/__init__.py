@@ -7,11 +7,12 @@ host-side mirror of the reference interface.  No CPU fallback.
 """
 from ._lib import LIB_PATH, HipLibraryMissing  # noqa: F401
 from .autoencoder import HipAutoencoder  # noqa: F401
+from .image_encoder import HipImageEncoder  # noqa: F401
 from .denoiser import HipDenoiser, HipEngine, WindowCache  # noqa: F401
 from .scheduler import ClassifierFreeGuidance, HipSchedulerFlow  # noqa: F401
 from .sharding import FrameShardPlan  # noqa: F401
 from .windows import LatentBank, chunk_from, denoise_window, generate_3d_latents  # noqa: F401
 
-__all__ = ["HipAutoencoder", "HipDenoiser", "HipEngine", "HipSchedulerFlow", "ClassifierFreeGuidance",
+__all__ = ["HipAutoencoder", "HipImageEncoder", "HipDenoiser", "HipEngine", "HipSchedulerFlow", "ClassifierFreeGuidance",
            "FrameShardPlan", "WindowCache", "HipLibraryMissing", "LIB_PATH",
            "LatentBank", "chunk_from", "denoise_window", "generate_3d_latents"]

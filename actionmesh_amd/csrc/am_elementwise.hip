@@ -128,6 +128,41 @@ __global__ void displacement_kernel(const bf16_t* __restrict__ logits, int ld, i
   out[i] = 2.0f / (1.0f + __expf(-x)) - 1.0f;
 }
 
+// ---- context encoder (transformers Dinov2PatchEmbeddings: Conv2d with kernel = stride = patch) ------------------------
+// im2col of the stride = kernel convolution: out[t * nh * nw + py * nw + px][c * p * p + ky * p + kx] = pix[t][c][py p + ky][px p + kx]
+// (the column order of a flattened Conv2d weight), bf16, zero padded to ld_out so the patch projection is one GEMM.
+__global__ void patchify_kernel(const float* __restrict__ pix, int ch, int H, int W, int patch, int nh, int nw, int64_t rows,
+                                bf16_t* __restrict__ out, int ld_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld_out) return;
+  const int64_t row = i / ld_out;
+  const int c = (int)(i - row * ld_out);
+  float v = 0.f;
+  if (c < ch * patch * patch) {
+    const int64_t t = row / (nh * nw);
+    const int pr = (int)(row - t * nh * nw);
+    const int py = pr / nw, px = pr - py * nw;
+    const int cc = c / (patch * patch), k = c - cc * patch * patch;
+    const int ky = k / patch, kx = k - ky * patch;
+    v = pix[((t * ch + cc) * H + py * patch + ky) * (int64_t)W + px * patch + kx];
+  }
+  out[i] = f2bf(v);
+}
+
+extern "C" int am_patchify(const float* pixels, int frames, int channels, int height, int width, int patch, uint16_t* out,
+                           int ld_out, void* stream) {
+  AM_CHECK(pixels && out && frames > 0 && channels > 0 && patch > 0, "am_patchify: bad args");
+  AM_CHECK(height >= patch && width >= patch, "am_patchify: image %dx%d smaller than one patch (%d)", height, width, patch);
+  AM_CHECK(ld_out >= channels * patch * patch, "am_patchify: ld_out=%d too small", ld_out);
+  const int nh = height / patch, nw = width / patch;
+  const int64_t rows = (int64_t)frames * nh * nw;
+  const int64_t n = rows * ld_out;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)ceil_div(n, (int64_t)256)), dim3(256), 0, (hipStream_t)stream, pixels,
+                     channels, height, width, patch, nh, nw, rows, out, ld_out);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 extern "C" int am_point_embed(const float* q_dev, int ld_in, int64_t rows, int in_channels, int extra_channels, int num_freqs,
                               int include_pi, uint16_t* out, int ld_out, void* stream) {
   AM_CHECK(q_dev && out && rows > 0, "am_point_embed: bad args");

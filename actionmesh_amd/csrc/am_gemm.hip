@@ -399,7 +399,10 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   const bool force_small = (args.act & 0x100) != 0;
   args.act &= 0xff;
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
-  const bool big = !force_small && args.N >= 256 && args.M >= 1024;
+  // the 256x256 tiles need a grid that fills the 256 CUs; mid-sized problems (the context encoder's 16 x 257 rows)
+  // get four times as many 128x128 workgroups instead
+  const bool big = !force_small && args.N >= 256 && args.M >= 1024 &&
+                   (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192;
   if (big) {
     // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
     // frame): a last 256-row tile holding a few rows would cost a whole extra round of workgroups.

@@ -191,6 +191,16 @@ def point_embed(query: torch.Tensor, in_channels: int, extra_channels: int, num_
     return out
 
 
+def patchify(pixels: torch.Tensor, patch: int, ld_out: int) -> torch.Tensor:
+    """pixels (T, C, H, W) fp32 -> bf16 (T * (H // patch) * (W // patch), ld_out): rows of the kernel = stride patch
+    convolution in flattened-Conv2d-weight column order, zero padded."""
+    _need(pixels, torch.float32, "pixels")
+    T, Cin, H, W = pixels.shape
+    out = torch.empty((T * (H // patch) * (W // patch), ld_out), dtype=torch.bfloat16, device=pixels.device)
+    L.check(L.lib().am_patchify(pixels.data_ptr(), T, Cin, H, W, patch, out.data_ptr(), ld_out, _stream()), "am_patchify")
+    return out
+
+
 def displacement(logits: torch.Tensor, out_dim: int, out: torch.Tensor) -> torch.Tensor:
     """out (rows, out_dim) fp32 = 2 sigmoid(-logits[:, :out_dim]) - 1."""
     _need(logits, torch.bfloat16, "logits"); _need(out, torch.float32, "out")

@@ -225,6 +225,12 @@ int am_point_embed(const float* q_dev, int ld_in, int64_t rows, int in_channels,
                    int include_pi, uint16_t* out, int ld_out, void* stream);
 int am_displacement(const uint16_t* logits, int ld, int64_t rows, int out_dim, float* out, void* stream);
 
+/* Context encoder (image_encoder.py:38-55 -> transformers Dinov2PatchEmbeddings): im2col of the kernel = stride patch
+ * convolution, pixels (frames, channels, height, width) fp32 -> bf16 (frames * (height/patch) * (width/patch), ld_out),
+ * columns in flattened-Conv2d-weight order (c, ky, kx), zero padded to ld_out; the projection itself is am_gemm_bf16. */
+int am_patchify(const float* pixels, int frames, int channels, int height, int width, int patch, uint16_t* out,
+                int ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

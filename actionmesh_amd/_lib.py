@@ -82,6 +82,7 @@ SYMBOLS = {
     "am_forward_begin": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "am_point_embed": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "am_displacement": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "am_attention_fallback_count": (C.c_int, [_P]),
     "am_patchify": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "am_layer_pre_attn": (C.c_int, [_P, C.c_int, _P]),
     "am_layer_attn_local": (C.c_int, [_P, C.c_int, _P]),

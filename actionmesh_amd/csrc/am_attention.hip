@@ -695,9 +695,10 @@ int launch(const am_attn_args* a, void* stream) {
 int am_attention_variant(const am_attn_args* a, void* stream);   // am_attention_variants.hip
 #endif
 
-// defer_log2: 0 or 8 = deferred-rescale threshold in log2 units (0 = rescale whenever a max grows).
+// defer_log2: 0 = exact online softmax, re-based whenever a row max grows; 8 = product: deferred re-base (threshold 2^8)
+// on the 8-wave kernel, the lazy re-base of am_attention64.hip (+ its exact fallback launch) on the 4x64 kernel.
 // Other codes force one kernel for A/B runs and parity tests: +60 the 4x64 kernel, +90 the 8-wave kernel,
-// +50 / +70 its geometry / schedule variants.
+// +50 / +70 its geometry / schedule variants; 28 = the 4x64 kernel with the exact deferred re-base on its own.
 // Builds with -DAM_ATTN_ABLATIONS also accept the experimental schedules of am_attention_variants.hip
 // (defer_log2 >= 100, used by tools/kernel_bench.py for A/B measurements).
 extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
@@ -722,7 +723,7 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   AM_CHECK(a->chunk_total == 0 || (a->rows == 1 && a->chunk_total > 0 && a->chunk_first >= 0 && a->chunk_first < a->chunk_total &&
                                    a->nchunks <= a->chunk_total),
            "am_attention_bf16: chunk_first/chunk_total need rows = 1, 0 <= first < total, nchunks <= total");
-  AM_CHECK(a->rows != 1 || a->defer_log2 == 0 || a->defer_log2 == 8 || a->defer_log2 == 60 || a->defer_log2 == 68,
+  AM_CHECK(a->rows != 1 || a->defer_log2 == 0 || a->defer_log2 == 8 || a->defer_log2 == 60 || a->defer_log2 == 68 || a->defer_log2 == 28,
            "am_attention_bf16: rows = 1 runs on the product dispatch only");
   switch (a->defer_log2) {
     case 0: return launch<0, 8, 2, 3>(a, stream);
@@ -733,6 +734,7 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
     case 58: return launch<8, 4, 1>(a, stream);
     case 60: return launch<0, 8, 2, 2>(a, stream);   // 4 waves x 64 rows, one wave per SIMD (am_attention64.hip)
     case 68: return launch<8, 8, 2, 2>(a, stream);
+    case 28: return launch<8, 8, 2, 2>(a, stream);   // same kernel family, exact deferred re-base (no lazy pass)
     case 70: return launch<0, 8, 2, 1>(a, stream);   // balanced two-phase schedule
     case 78: return launch<8, 8, 2, 1>(a, stream);
     default:

@@ -19,7 +19,7 @@
 //     s_waitcnt vmcnt(8); fragments sit in explicit rotating register sets with HOLD() keep-alives;
 //   * the padded keys of a chunk's partial last tile score exactly 0 and their exp2(-m) is removed from the
 //     row sums once, after the loop (rescales multiply it like every other term);
-//   * O (128) and the pre-scaled Q (64) live in AccVGPRs a[0:191], named literally in the inline asm of
+//   * O (128) and the pre-scaled Q (64) live in AccVGPRs a[64:255], named literally in the inline asm of
 //     am_attention64_asm.inc (P.V runs as AGPR-form MFMAs, QK^T takes its B operand from the accumulator file);
 //   * two-pass form for the multi-GPU overlap (STATE): save (O, m, l) after the local key chunk, resume over
 //     the remote chunks in ring order (am_attn_args.state_mode / chunk_first / chunk_total).
@@ -95,6 +95,54 @@ __device__ __host__ constexpr EsTab es_make_tab() {
   return t;
 }
 
+// LAZY kernels have no row-max pass in front of the exponentials, so a phase spreads its 80 steps over all 32 MFMA gaps.
+// Gap capacities (issue slots left beside what else the gap holds): a gap with an LDS-DMA piece / a fragment read gets
+// fewer steps.  pv = true: the P.V phase (pieces in the even gaps 0..6, reads in gaps 0..3 of every k-step);
+// false: the QK^T phase (pieces in even gaps 0..6, a read in every odd gap).
+#ifndef AM_ES_CAP_FULL
+#define AM_ES_CAP_FULL 8
+#endif
+#ifndef AM_ES_CAP_DMA
+#define AM_ES_CAP_DMA 3
+#endif
+#ifndef AM_ES_CAP_READ
+#define AM_ES_CAP_READ 7
+#endif
+struct EsTab32 { int lo[33]; };
+__device__ __host__ constexpr int es_cap32(bool pv, int gap) {
+  const bool dma = gap < 8 && (gap & 1) == 0;
+  const bool rd = pv ? (gap & 7) < 4 : (gap & 1) == 1;
+  return dma ? AM_ES_CAP_DMA : rd ? AM_ES_CAP_READ : AM_ES_CAP_FULL;
+}
+__device__ __host__ constexpr EsTab32 es_make_tab32(bool pv) {
+  int cum[33] = {};
+  for (int i = 0; i < 32; ++i) cum[i + 1] = cum[i] + es_cap32(pv, i);
+  EsTab32 t{};
+  int n = 0;
+  for (int i = 0; i <= 32; ++i) {        // steps whose cumulative cost starts below cum[i] / cum[32] of the total go before gap i
+    while (n < 80 && es_cost_before(n) * cum[32] < cum[i] * 112) ++n;
+    t.lo[i] = n;
+  }
+  t.lo[32] = 80;
+  return t;
+}
+
+#ifndef AM_LAZY_X1
+#define AM_LAZY_X1 0
+#endif
+#ifndef AM_LAZY_X2
+#define AM_LAZY_X2 0
+#endif
+#ifndef AM_LAZY_X3
+#define AM_LAZY_X3 0
+#endif
+__device__ __host__ constexpr EsTab32 es_tab32_late() {      // experiment: nothing in the first 8 gaps, the 24-gap table after
+  EsTab32 t{};
+  const EsTab o = es_make_tab();
+  for (int i = 0; i <= 32; ++i) t.lo[i] = i < 8 ? 0 : o.lo[i - 8];
+  return t;
+}
+
 template <int ABL>
 struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, skewed by one pair
   float rs[4];
@@ -135,9 +183,24 @@ struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, 
 // STATE (two-pass attention, am_attn_args.state_mode): 0 = one pass; 1 = save the un-normalised (O, m, l) of every row
 // to p.state instead of writing O; 2 = resume from p.state, finish, write O.
 constexpr int STATE_LD = 132;      // floats per saved row: O[128], m, l, pad (16-byte aligned rows)
-template <int DEFER, int ABL = 0, bool PROF = false, int STATE = 0>
-__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk, unsigned long long* prof) {
+// LAZY: no row max at all.  m_run starts at 0 (scores in log2 units); the scores of a tile are exponentiated relative to the
+// m_run they were born with; the tile's row sums (computed anyway) tell afterwards whether m_run has fallen behind
+// (sum > 2^12), and the rare re-base multiplies O, l and the not yet consumed P by an exact power of two and moves m_run up
+// by that many octaves.  fp32 and bf16 share an 8-bit exponent, so a lag of up to 2^60 loses nothing.  What this cannot
+// represent - a single-tile jump beyond 2^60, a non-finite sum, a row whose scores all sit more than ~100 octaves below
+// m_run (final sum under 2^-100) - marks the workgroup in `flags`, and the exact kernel (LAZY = false, same grid, launched
+// behind it) recomputes the marked workgroups and clears the marks.
+constexpr float LAZY_T = 4096.f;
+__device__ __forceinline__ bool tid_is_zero() { return __builtin_amdgcn_workitem_id_x() == 0; }
+template <int DEFER, int ABL = 0, bool PROF = false, int STATE = 0, bool LAZY = false>
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int tiles_per_chunk, unsigned long long* prof,
+                                                            unsigned* flags, int flag_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int flag_idx = __builtin_amdgcn_workgroup_id_y() * flag_stride + __builtin_amdgcn_workgroup_id_x();
+  if (!LAZY && flags != nullptr) {                                    // fallback launch: only the marked workgroups run
+    if (flags[flag_idx] == 0) return;
+    if (tid_is_zero()) atomicAdd(flags - 4, 1u);                      // diagnostic: am_attention_fallback_count
+  }
   const int tid = __builtin_amdgcn_workitem_id_x();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     }
   };
 
-  // ---- Q fragments (B operand) of both query blocks, pre-scaled to log2 units, parked in a[128:191] ----
+  // ---- Q fragments (B operand) of both query blocks, pre-scaled to log2 units, parked in a[192:255] ----
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + q0 + 32 * j + l31) * HD + hi * 8;
@@ -300,6 +363,130 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
     for (int d = 0; d < 4; ++d) vf[0][d] = v_frag(smem + 3 * STAGE_B, d, 0);
     asm volatile("" :: "v"(negm[0]), "v"(negm[1]));     // SrcC of the first k-step stays allocated until here
+  };
+  bool poison = false;
+  uint64_t ok1_prev = ~0ull;
+  float part1_prev = 0.f;
+  // rare (LAZY): m_run of block j has fallen behind by more than 2^12 - move it up by a whole number of octaves.
+  // w = a P tile that has been computed but not consumed yet (nullptr: none), snext = the block's next scores
+  // (accumulated, or still accumulating - their MFMAs may be in flight -, not yet exponentiated).
+  auto lazy_rebase = [&](int j, float part, u32x4_t (*w)[4], f32x16_t* snext) __attribute__((always_inline)) {
+#ifdef AM_LAZY_DEBUG
+    if (lane == 0) atomicAdd(flags - 3 + j, 1u);
+#endif
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+    const float rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // the row's sum over the tile, same in both half-lanes
+    const bool bad = !(rs < 0x1p60f);
+    poison |= bad;
+    const int e = bad ? 0 : max(__builtin_amdgcn_frexp_expf(rs), 0);
+    const float delta = (float)e;
+    const float alpha = __builtin_amdgcn_exp2f(-delta);                    // exact
+    m_run[j] += delta;
+    l_run[j] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[j][r] = -m_run[j];
+    FENCE();                            // the rare path runs with every register of the loop live: keep its temporaries few
+    o_scale(j, alpha);
+    if (w != nullptr) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) (*w)[kk][i] = pack_bf2(bflo((*w)[kk][i]) * alpha, bfhi((*w)[kk][i]) * alpha);
+        FENCE();
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(snext[0]), "+v"(snext[1]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { snext[0][r] -= delta; snext[1][r] -= delta; }
+    FENCE();
+  };
+
+  // ---- one tile, LAZY form: phase 1 = 32 P.V MFMAs || the whole softmax of block 0, phase 2 = 32 QK^T MFMAs || the
+  //      whole softmax of block 1; fragment reads, DMA pieces and register sets exactly as in the exact form below ----
+  auto iteration_lazy = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
+                            u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
+    stamp(g, 0);
+    if (g > 0) { advance(kcur); advance(vcur); }
+    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stamp(g, 1);
+    const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
+    const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
+    const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
+    ExpSumPackT<ABL> es;
+    constexpr EsTab32 ES1 = AM_LAZY_X3 ? es_tab32_late() : es_make_tab32(true), ES2 = AM_LAZY_X2 ? es_tab32_late() : es_make_tab32(false);
+    auto bf = [](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
+    // ===== phase 1: O += V^T(g-1) P^T(g-1) || softmax of block 0; K(g+3) DMA; K(g+1) prefetch =====
+    stamp(g, 2);
+    es.init();
+    FENCE();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int gap = (kk * 4 + d) * 2;
+        pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
+        if (kk == 0) dma_k(d);                                  // one LDS-DMA piece per MFMA pair
+        if (d < 2) {                                            // next fragments in gaps 0..3 of the step: landed by its end
+          if (kk < 3) vf[(kk + 1) & 1][2 * d] = v_frag(v_st, 2 * d, kk + 1);
+          else kf[d][0] = k_frag(k_st, 0, d);
+        }
+        if (!(ABL & (8 | 32)))
+#pragma unroll
+          for (int n = ES1.lo[gap]; n < ES1.lo[gap + 1]; ++n) es.step(n, s0[0], s0[1], p0n);
+        FENCE();
+        pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
+        if (d < 2) {
+          if (kk < 3) vf[(kk + 1) & 1][2 * d + 1] = v_frag(v_st, 2 * d + 1, kk + 1);
+          else kf[d][1] = k_frag(k_st, 1, d);
+        }
+        if (!(ABL & (8 | 32)))
+#pragma unroll
+          for (int n = ES1.lo[gap + 1]; n < ES1.lo[gap + 2]; ++n) es.step(n, s0[0], s0[1], p0n);
+        FENCE();
+      }
+      HOLD4(vf[kk & 1][0], vf[kk & 1][1], vf[kk & 1][2], vf[kk & 1][3]);
+    }
+    stamp(g, 4);
+    const float part0 = es.total();
+    l_run[0] += part0;
+    uint64_t ok0 = __builtin_amdgcn_ballot_w64(part0 <= LAZY_T);    // evaluated here, branched on a phase later:
+    asm volatile("" : "+s"(ok0));                                   // no VALU -> branch latency in the loop
+    // block 1, previous tile: its P has just been consumed (O and l agree), S(g) is not exponentiated yet
+    if (!AM_LAZY_X1 && ok1_prev != ~0ull) lazy_rebase(1, part1_prev, nullptr, s1c);
+    // ===== phase 2: S(g+1) = K(g+1) Q^T || softmax of block 1; V^T(g+2) DMA; V^T(g) prefetch =====
+    es.init();
+    FENCE();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int gap = (ks * 2 + kb) * 2;
+        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks % 3][kb], negm[0]);
+        else qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
+        if (ks < 2) dma_v(ks * 2 + kb);
+        if (!(ABL & (8 | 64)))
+#pragma unroll
+          for (int n = ES2.lo[gap]; n < ES2.lo[gap + 1]; ++n) es.step(n, s1c[0], s1c[1], p1);
+        FENCE();
+        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks % 3][kb], negm[1]);
+        else qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
+        if (ks < 6) kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);      // into the set the previous k-step has finished with
+        else vf[0][(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
+        if (!(ABL & (8 | 64)))
+#pragma unroll
+          for (int n = ES2.lo[gap + 1]; n < ES2.lo[gap + 2]; ++n) es.step(n, s1c[0], s1c[1], p1);
+        FENCE();
+      }
+      HOLD2(kf[ks % 3][0], kf[ks % 3][1]);
+    }
+    stamp(g, 6);
+    const float part1 = es.total();
+    l_run[1] += part1;
+    // block 0, this tile: P(g) is computed but not consumed, S(g+1) is accumulated
+    if (!AM_LAZY_X1 && ok0 != ~0ull) lazy_rebase(0, part0, &p0n, s0);
+    ok1_prev = __builtin_amdgcn_ballot_w64(part1 <= LAZY_T);
+    part1_prev = part1;
+    asm volatile("" : "+s"(ok1_prev));
   };
 
   // ---- one tile.  cur = ping-pong set holding S(g) of block 1 and P(g-1) of block 0 ----
@@ -450,36 +637,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   };
 
   // ---- main loop, two tiles per trip so the ping-pong sets are compile-time names ----
-  int g = 0;
-  if (n_tiles & 1) {
-    first_scores(s1[1]);
-    iteration(0, s1[1], s1[0], p0[1], p0[0]);
-    g = 1;
-  } else {
-    first_scores(s1[0]);
-  }
-  for (; g < n_tiles; g += 2) {
-    iteration(g, s1[0], s1[1], p0[0], p0[1]);
-    iteration(g + 1, s1[1], s1[0], p0[1], p0[0]);
-  }
-
-  // The last iteration's QK^T MFMAs (scores of a tile that does not exist) are still in flight and hipcc does
-  // not know they are MFMAs: hold their destination registers until the results have landed, or the epilogue's
-  // temporaries allocated there are overwritten (MFMA D -> any writer: 12 wait states).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA piece may outlive the workgroup's LDS allocation
-  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0][0]), "+v"(s1[0][1]), "+v"(s1[1][0]), "+v"(s1[1][1]));
-
-  // ---- drain: O += V^T(n-1) P^T(n-1)  (P of block 0 is in p0[0] after an odd-set iteration) ----
-  {
+  auto tile = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4], u32x4_t (&p0n)[4])
+      __attribute__((always_inline)) {
+    if constexpr (LAZY) iteration_lazy(g, s1c, s1n, p0c, p0n);
+    else iteration(g, s1c, s1n, p0c, p0n);
+  };
+  // Odd tile counts take their extra tile after the loop (peeled in front of it, the two entry paths meet with every
+  // register of the pipeline live in different roles, and hipcc parks dozens of values in AccVGPRs to reconcile them).
+  auto finish = [&](u32x4_t (&p0last)[4]) __attribute__((always_inline)) {
+    // The last iteration's QK^T MFMAs (scores of a tile that does not exist) are still in flight and hipcc does
+    // not know they are MFMAs: hold their destination registers until the results have landed, or the epilogue's
+    // temporaries allocated there are overwritten (MFMA D -> any writer: 12 wait states).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA piece may outlive the workgroup's LDS allocation
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0][0]), "+v"(s1[0][1]), "+v"(s1[1][0]), "+v"(s1[1][1]));
+    // drain: O += V^T(n-1) P^T(n-1)
     const unsigned char* v_st = smem + ((n_tiles + 3) & 3) * STAGE_B;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const bf16x8_t vfr = kk == 0 ? vf[0][d] : v_frag(v_st, d, kk);
-        pv_mfma(d, vfr, __builtin_bit_cast(bf16x8_t, p0[0][kk]));
+        pv_mfma(d, vfr, __builtin_bit_cast(bf16x8_t, p0last[kk]));
         pv_mfma(4 + d, vfr, __builtin_bit_cast(bf16x8_t, p1[kk]));
       }
+  };
+  first_scores(s1[0]);
+  int g = 0;
+  for (; g + 1 < n_tiles; g += 2) {
+    tile(g, s1[0], s1[1], p0[0], p0[1]);
+    tile(g + 1, s1[1], s1[0], p0[1], p0[0]);
+  }
+  if (g < n_tiles) {
+    tile(g, s1[0], s1[1], p0[0], p0[1]);
+    finish(p0[1]);
+  } else {
+    finish(p0[0]);
   }
   o_read_fence();
 
@@ -496,6 +688,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   for (int j = 0; j < 2; ++j) {
     float l = l_run[j] - (float)(cnt * p.nchunks) * __builtin_amdgcn_exp2f(-m_run[j]);
     l += __shfl_xor(l, 32);
+    // LAZY: m_run starts at 0 (or at the saved state's) and only ever moves up by whole octaves when a row sum says so.
+    // A row whose scores all sit far below it has lost its sum to underflow: let the exact kernel redo the workgroup.
+    if (LAZY) poison |= !(l >= 0x1p-100f && l < 0x1p100f);
     const int q = q0 + 32 * j + l31;
     if (STATE == 1) {          // first pass of two: save (O, m, l), every row of the padded block
       float* sp = p.state + ((int64_t)bh * p.sq_pad + q) * STATE_LD;
@@ -521,21 +716,85 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         }
     }
   }
+  if (LAZY) {                 // a jump the lazy re-base cannot represent: have the exact kernel redo this workgroup
+    if (__any(poison) && lane == 0) flags[flag_idx] = 1u;
+  } else if (flags != nullptr && tid == 0) {
+    flags[flag_idx] = 0u;     // every wave read the mark before its first barrier
+  }
 }
 
 }  // namespace
 
+// Per-device mark buffer of the LAZY kernel (one word per workgroup, all zero between launches: the exact fallback
+// clears what the lazy pass set).  Grow-only; launches on one device are issued from one thread (C-ABI contract).
+static unsigned* g_flag_buf[64] = {};      // [0] = workgroups the exact fallback has recomputed so far, [4..] = marks
+static int64_t g_flag_cap[64] = {};
+static int lazy_flags(int64_t n, unsigned** out) {
+  int dev = 0;
+  AM_HIP(hipGetDevice(&dev));
+  AM_CHECK(dev >= 0 && dev < 64, "am_attention64: device index %d", dev);
+  if (g_flag_cap[dev] < n) {
+    unsigned count = 0;
+    if (g_flag_buf[dev]) {
+      AM_HIP(hipDeviceSynchronize());
+      AM_HIP(hipMemcpy(&count, g_flag_buf[dev], sizeof(count), hipMemcpyDeviceToHost));
+      AM_HIP(hipFree(g_flag_buf[dev]));
+    }
+    g_flag_cap[dev] = n > (1 << 18) ? n : (1 << 18);
+    AM_HIP(hipMalloc(&g_flag_buf[dev], (g_flag_cap[dev] + 4) * sizeof(unsigned)));
+    AM_HIP(hipMemset(g_flag_buf[dev], 0, (g_flag_cap[dev] + 4) * sizeof(unsigned)));
+    AM_HIP(hipMemcpy(g_flag_buf[dev], &count, sizeof(count), hipMemcpyHostToDevice));
+  }
+  *out = g_flag_buf[dev] + 4;
+  return AM_OK;
+}
+// Diagnostic (tests): number of workgroups of the current device the exact fallback kernel has recomputed since the
+// library was loaded.  Synchronises the device.
+extern "C" int am_attention_fallback_count(uint64_t* count) {
+  AM_CHECK(count != nullptr, "am_attention_fallback_count: null argument");
+  int dev = 0;
+  AM_HIP(hipGetDevice(&dev));
+  AM_CHECK(dev >= 0 && dev < 64, "am_attention_fallback_count: device index %d", dev);
+  unsigned c = 0;
+  if (g_flag_buf[dev]) {
+    AM_HIP(hipDeviceSynchronize());
+    AM_HIP(hipMemcpy(&c, g_flag_buf[dev], sizeof(c), hipMemcpyDeviceToHost));
+#ifdef AM_LAZY_DEBUG
+    unsigned r[2] = {0, 0};
+    AM_HIP(hipMemcpy(r, g_flag_buf[dev] + 1, sizeof(r), hipMemcpyDeviceToHost));
+    *count = (uint64_t)c | ((uint64_t)r[0] << 20) | ((uint64_t)r[1] << 40);
+    return AM_OK;
+#endif
+  }
+  *count = c;
+  return AM_OK;
+}
+
 // Main (non-split) grid of the 4x64 kernel: query blocks [0, nblk_main) of every (sequence, head).
-template <int DEFER, int ABL, int STATE>
+// LAZY: the lazy kernel, then the exact kernel over the same grid for the workgroups the lazy one marked (normally none:
+// its workgroups read one word and exit).
+template <int DEFER, int ABL, int STATE, bool LAZY = false>
 static int launch64(const am_attn_args* a, int tiles_per_chunk, int nblk_main, void* stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL, false, STATE>),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL, false, STATE, LAZY>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL, false, STATE>), dim3(nblk_main, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
-                     (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr);
+  unsigned* flags = nullptr;
+  if (LAZY) AM_TRY(lazy_flags((int64_t)nblk_main * a->nseq * a->heads, &flags));
+  hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL, false, STATE, LAZY>), dim3(nblk_main, a->nseq * a->heads), dim3(256),
+                     NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr, flags, nblk_main);
+  if (LAZY && ABL == 0) {
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, false, STATE, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, false, STATE, false>), dim3(nblk_main, a->nseq * a->heads), dim3(256),
+                       NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr, flags, nblk_main);
+  }
   return AM_OK;
 }
 int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
@@ -557,11 +816,20 @@ int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_mai
     default: break;
   }
 #endif
+  // defer > 0: the lazy kernel (+ exact fallback); defer == 0: the exact kernel with an immediate re-base;
+  // a->defer_log2 == 28: the exact kernel with the deferred re-base on its own (A/B, tests)
+  const bool exact = a->defer_log2 == 28;
   if (a->state_mode == 1)
-    return defer == 0 ? launch64<0, 0, 1>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 1>(a, tiles_per_chunk, nblk_main, stream);
+    return defer == 0 ? launch64<0, 0, 1>(a, tiles_per_chunk, nblk_main, stream)
+           : exact    ? launch64<8, 0, 1>(a, tiles_per_chunk, nblk_main, stream)
+                      : launch64<8, 0, 1, true>(a, tiles_per_chunk, nblk_main, stream);
   if (a->state_mode == 2)
-    return defer == 0 ? launch64<0, 0, 2>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 2>(a, tiles_per_chunk, nblk_main, stream);
-  return defer == 0 ? launch64<0, 0, 0>(a, tiles_per_chunk, nblk_main, stream) : launch64<8, 0, 0>(a, tiles_per_chunk, nblk_main, stream);
+    return defer == 0 ? launch64<0, 0, 2>(a, tiles_per_chunk, nblk_main, stream)
+           : exact    ? launch64<8, 0, 2>(a, tiles_per_chunk, nblk_main, stream)
+                      : launch64<8, 0, 2, true>(a, tiles_per_chunk, nblk_main, stream);
+  return defer == 0 ? launch64<0, 0, 0>(a, tiles_per_chunk, nblk_main, stream)
+         : exact    ? launch64<8, 0, 0>(a, tiles_per_chunk, nblk_main, stream)
+                    : launch64<8, 0, 0, true>(a, tiles_per_chunk, nblk_main, stream);
 }
 
 #ifdef AM_ATTN_ABLATIONS
@@ -571,7 +839,7 @@ extern "C" int am_attention64_profile(const am_attn_args* a, unsigned long long*
                              hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, true>), dim3(ceil_div(a->sq, QBLK), a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
-                     (hipStream_t)stream, *a, tiles_per_chunk, prof_dev);
+                     (hipStream_t)stream, *a, tiles_per_chunk, prof_dev, (unsigned*)nullptr, 0);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

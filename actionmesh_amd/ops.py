@@ -165,6 +165,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
     return out
 
 
+def attention_fallback_count() -> int:
+    """Workgroups the exact fallback of the lazy attention kernel has recomputed so far on the current device."""
+    n = C.c_uint64(0)
+    L.check(L.lib().am_attention_fallback_count(C.byref(n)), "am_attention_fallback_count")
+    return int(n.value)
+
+
 def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
     _need(x, torch.float32, "x")
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

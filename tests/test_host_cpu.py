@@ -148,9 +148,10 @@ def test_perm16_is_an_involution_matching_the_mfma_layout():
 
 
 def test_attn64_register_audit(tmp_path):
-    """The 4x64 attention kernel names AccVGPRs a[0:191] literally in inline asm (O accumulators, Q fragments).
-    That is only sound if hipcc itself never touches a[0:191] in that kernel: no scratch spills, and every
-    compiler-generated AccVGPR access (it may park spilled values in a192+) outside the asm-owned range
+    """The 4x64 attention kernel names AccVGPRs a[64:255] literally in inline asm (O accumulators, Q fragments).
+    That is only sound if hipcc itself never touches a[64:255] in that kernel: no scratch spills, and every
+    compiler-generated AccVGPR access (when the kernel needs more than 256 arch VGPRs the allocator parks values in
+    AccVGPRs, lowest free first, whatever the asm clobber lists say) inside a[0:63], which the asm leaves alone
     (tools/gen_attn64_asm.py; cdna guide 'keep out of registers you name')."""
     import shutil
     import subprocess
@@ -171,9 +172,9 @@ def test_attn64_register_audit(tmp_path):
         kernels = [(a, n, p) for a, n, p in zip(re.findall(r"\.agpr_count:\s+(\d+)", text), names,
                                                 re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))]
     for agprs, name, scratch in kernels:
-        assert int(agprs) >= 192, f"{name}: {agprs} AccVGPRs allocated, the asm owns a[0:191]"
+        assert int(agprs) == 256, f"{name}: {agprs} AccVGPRs allocated, the asm owns a[64:255]"
         assert int(scratch) == 0, f"{name}: spills to scratch ({scratch} B)"
-    # hipcc may park spilled values in AccVGPRs of its own (a192 and up) - never in the asm-owned range
+    # hipcc may park values in AccVGPRs of its own (a0..a63) - never in the asm-owned range
     in_asm = False
     for ln in text.splitlines():
         code = ln.split(";")[0]
@@ -184,4 +185,34 @@ def test_attn64_register_audit(tmp_path):
         elif not in_asm and re.match(r"\s+(v_|ds_|global_|buffer_|scratch_|flat_)", code):
             for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", code):
                 lo = int(m.group(1) if m.group(1) is not None else m.group(3))
-                assert lo >= 192, f"compiler-generated access to an asm-owned AccVGPR: {ln.strip()}"
+                hi_ = int(m.group(2)) if m.group(2) is not None else lo
+                assert hi_ < 64, f"compiler-generated access to an asm-owned AccVGPR: {ln.strip()}"
+    # hipcc does not know the asm statements are MFMAs: nothing it generates (copies, parking in AccVGPRs, softmax steps)
+    # may touch the arch-VGPR destination of a QK^T MFMA within the 11 wait states an 8-pass MFMA needs (14 checked)
+    def vregs(tok):
+        out = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1) if m.group(1) is not None else [int(m.group(3))])
+        return out
+    in_asm, hot = False, {}
+    for ln in text.splitlines():
+        code = ln.split(";")[0].rstrip()
+        if "#ASMSTART" in ln:
+            in_asm = True
+            continue
+        if "#ASMEND" in ln:
+            in_asm = False
+            continue
+        m = re.match(r"\s+([a-z]\S*)\s*(.*)", code)
+        if not m:
+            if re.match(r"\S+:", code):
+                hot = {}                      # label: textual order is not execution order beyond this point
+            continue
+        op, args = m.group(1), m.group(2)
+        step = int(args.strip()) + 1 if op == "s_nop" else 1
+        if not in_asm and op != "s_nop":
+            touched = vregs(args) & set(hot)
+            assert not touched, f"compiler-generated access to an in-flight MFMA result: {ln.strip()}"
+        hot = {k: v - step for k, v in hot.items() if v - step > 0}
+        if in_asm and op.startswith("v_mfma") and args.split(",")[0].strip().startswith("v"):
+            hot.update({r: 14 for r in vregs(args.split(",")[0])})

@@ -240,8 +240,9 @@ def _sdpa_ref(q, k, v):
                                                   (1, 2, 520, 1040, 4), (2, 8, 2049, 257, 1),
                                                   # short last query block -> split-KV tail path (+ chunks)
                                                   (1, 2, 2320, 4200, 1), (2, 1, 2305, 4224, 2), (1, 1, 2432, 4097, 1)])
-# 0/8: product dispatch; 60/68: forced 4 waves x 64 rows; 90/98: forced 8-wave kernel; 58: 2 x 4-wave geometry; 78: balanced two-phase
-@pytest.mark.parametrize("defer", [0, 8, 60, 68, 90, 98, 58, 78])
+# 0/8: product dispatch; 60/68: forced 4 waves x 64 rows (68 = lazy re-base + exact fallback, 28 = exact deferred re-base);
+# 90/98: forced 8-wave kernel; 58: 2 x 4-wave geometry; 78: balanced two-phase
+@pytest.mark.parametrize("defer", [0, 8, 28, 60, 68, 90, 98, 58, 78])
 def test_attention(dev, nseq, H, sq, sk, nchunks, defer):
     from actionmesh_amd import ops
     q = _randn((nseq, H, sq, 128), 1, dev).to(torch.bfloat16)
@@ -306,6 +307,61 @@ def test_attention_forced_rescale_branch(dev):
             assert (o - ref).abs().max().item() < 3e-2, f"defer={defer}"
             outs.append(o)
         assert (outs[0] - outs[1]).abs().max().item() < 3e-2
+
+
+def _plant(q, k, row, key, score):
+    """Make key `key` score ~`score` (natural-log units, after the 1/sqrt(128) scale) against query row `row` of head 0."""
+    k[0, 0, key] = q[0, 0, row] / q[0, 0, row].norm() ** 2 * score * 128 ** 0.5
+
+
+def test_attention_lazy_rebase_and_exact_fallback(dev):
+    """The long-key-stream kernel keeps no running row max in its loop: a tile's row sums tell afterwards that m_run
+    has fallen behind, and O / l / the pending P are multiplied by an exact power of two (jumps up to 2^60); a bigger
+    single-tile jump marks the workgroup and the exact kernel launched behind recomputes it.  Both paths must agree with
+    the fp32 softmax, the fallback must fire only when needed, and its marks must be cleared for the next launch."""
+    from actionmesh_amd import ops
+    nseq, H, sq, sk = 1, 2, 512, 2048           # 32 key tiles -> the 4x64 kernel under the product dispatch
+    q = _randn((nseq, H, sq, 128), 1, dev)
+    v = _randn((nseq, H, sk, 128), 3, dev)
+
+    def run(k, defer=8):
+        qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+        Q, K, Vt, skc = _layout(qb, kb, vb, 1)
+        out = ops.attention(Q, K, Vt, sq, skc, defer_log2=defer).float()
+        ref = _sdpa_ref(qb, kb, vb).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+        return (out - ref).abs().max().item()
+
+    base = ops.attention_fallback_count()
+    # (a) moderate jumps, several per row, in both 32-row blocks of a wave and in both half-lanes' key halves
+    k = _randn((nseq, H, sk, 128), 2, dev) * 0.3
+    for (row, key, score) in ((7, 300, 12.0), (7, 900, 25.0), (7, 1990, 38.0), (40, 70, 9.0), (40, 100, 20.0),
+                              (100, 1500, 30.0), (300, 2047, 35.0), (511, 64, 15.0), (470, 1000, 22.0)):
+        _plant(q, k, row, key, score)
+    assert run(k) < 3e-2
+    assert ops.attention_fallback_count() == base, "jumps below 2^60 are the lazy re-base's job"
+    # (b) a single-tile jump of ~2^108 (75 nats): only the exact kernel can represent it
+    k2 = _randn((nseq, H, sk, 128), 2, dev) * 0.3
+    _plant(q, k2, 100, 1500, 75.0)
+    assert run(k2) < 3e-2
+    n1 = ops.attention_fallback_count()
+    assert n1 == base + 1, f"one workgroup (rows 0..255 of head 0) had to be recomputed, got {n1 - base}"
+    # (c) marks are cleared: an ordinary launch afterwards recomputes nothing, and the exact variants never mark
+    assert run(_randn((nseq, H, sk, 128), 4, dev)) < 2e-2
+    assert run(k2, defer=0) < 3e-2 and run(k2, defer=28) < 3e-2
+    assert ops.attention_fallback_count() == n1
+    # (d) two-pass form: the jump sits in the remote chunk of rank 0 (resume pass) and in the local chunk of rank 1
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k2, v))
+    Q, K, Vt, skc = _layout(qb, kb, vb, 2)
+    ref = _sdpa_ref(qb, kb, vb).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+    state = torch.zeros((nseq * H, Q.shape[2], ops.STATE_LD), device=dev)
+    for r in range(2):
+        out = torch.zeros((nseq * sq, H * 128), dtype=torch.bfloat16, device=dev)
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=1, rows=1, state_mode=1, state=state, chunk_first=r, chunk_total=2)
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=1, rows=1, state_mode=2, state=state, chunk_first=(r + 1) % 2,
+                      chunk_total=2)
+        ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=2, rows=2)
+        assert (out.float() - ref).abs().max().item() < 3e-2, f"rank {r}"
+    assert ops.attention_fallback_count() == n1 + 2
 
 
 def test_attention_properties_full_size(dev):

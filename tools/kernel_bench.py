@@ -46,7 +46,7 @@ def main():
         Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128)
         Vt = rnd(B, H, 128, ops.round_up(Sq, 64)); out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
         fl = 4.0 * Sq * Sq * C * B
-        for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64"), (a.defer + 90, "8-wave"), (a.defer + 70, "balanced"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
+        for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64 lazy"), (28, "4x64 exact"), (a.defer + 90, "8-wave"), (a.defer + 70, "balanced"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
                       (a.defer + 100, "staggered")):
             if d >= 100 and not a.variants:
                 continue

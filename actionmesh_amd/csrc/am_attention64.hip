@@ -78,24 +78,46 @@ struct RowMax {            // 20 steps: four v_max3 chains, cross-half swap
     } else { mx = __builtin_fmaxf(a[0], a[1]); PIN(mx); }
   }
 };
-// Issue-slot cost model for spreading the 80 exp/sum/pack steps over a phase's 24 MFMA gaps: a wave issues one
-// instruction per 4 cycles and v_exp_f32 holds the port for two slots (tools/ubench/mfma_fillers.hip), so a
-// step costs 2 (exp) or 1; gap i of 24 takes the steps whose cumulative cost starts in [112 i / 24, 112 (i+1) / 24).
-__device__ __host__ constexpr bool es_is_exp(int n) { return n < 2 || (n < 77 && (n - 2) % 5 < 2); }
-__device__ __host__ constexpr int es_cost_before(int n) { int c = 0; for (int i = 0; i < n; ++i) c += es_is_exp(i) ? 2 : 1; return c; }
-__device__ __host__ constexpr int es_gap_of(int n) { return es_cost_before(n) * 24 / 112; }
+// ---- exp / row sum / bf16 pack of one 32-query block as a sequence of 80 single-instruction steps: 32 v_exp_f32,
+// 32 v_add_f32 (row sum of the unrounded probabilities), 16 v_cvt_pk_bf16_f32; each op trails the exponentials it
+// depends on by a round.  (Tried: v_dot2c_f32_bf16 on the packed pairs instead of the adds - 64 steps - no faster.)
+enum EsKind : int { ES_EX = 0, ES_AD = 1, ES_PK = 2 };
+struct EsSeq { int n; int cost; int kind[80]; int arg[80]; };
+__device__ __host__ constexpr EsSeq es_make_seq() {
+  EsSeq q{};
+  int n = 0;
+  auto put = [&](int k, int a) { q.kind[n] = k; q.arg[n] = a; ++n; };
+  for (int r = 0; r < 16; ++r) {
+    put(ES_EX, 2 * r);
+    put(ES_EX, 2 * r + 1);
+    if (r >= 1) {
+      put(ES_AD, 2 * r - 2);
+      put(ES_AD, 2 * r - 1);
+      put(ES_PK, r - 1);
+    }
+  }
+  put(ES_AD, 30);
+  put(ES_AD, 31);
+  put(ES_PK, 15);
+  q.n = n;
+  // Issue-slot cost model for spreading the steps over a phase's MFMA gaps: a wave issues one instruction per 4 cycles
+  // and v_exp_f32 holds the port for two slots (tools/ubench/mfma_fillers.hip), so a step costs 2 (exp) or 1.
+  for (int i = 0; i < n; ++i) q.cost += q.kind[i] == ES_EX ? 2 : 1;
+  return q;
+}
+__device__ __host__ constexpr int es_cost_before(const EsSeq& q, int n) { int c = 0; for (int i = 0; i < n; ++i) c += q.kind[i] == ES_EX ? 2 : 1; return c; }
+// exact kernel: 24 gaps (phase b), gap i takes the steps whose cumulative cost starts in [cost i / 24, cost (i+1) / 24)
 struct EsTab { int lo[25]; };        // steps [lo[i], lo[i+1]) go into gap i
-__device__ __host__ constexpr EsTab es_make_tab() {
+__device__ __host__ constexpr EsTab es_make_tab(const EsSeq& q) {
   EsTab t{};
   for (int i = 0; i <= 24; ++i) {
     int n = 0;
-    while (n < 80 && es_gap_of(n) < i) ++n;
+    while (n < q.n && es_cost_before(q, n) * 24 / q.cost < i) ++n;
     t.lo[i] = n;
   }
   return t;
 }
-
-// LAZY kernels have no row-max pass in front of the exponentials, so a phase spreads its 80 steps over all 32 MFMA gaps.
+// LAZY kernels have no row-max pass in front of the exponentials, so a phase spreads its steps over all 32 MFMA gaps.
 // Gap capacities (issue slots left beside what else the gap holds): a gap with an LDS-DMA piece / a fragment read gets
 // fewer steps.  pv = true: the P.V phase (pieces in the even gaps 0..6, reads in gaps 0..3 of every k-step);
 // false: the QK^T phase (pieces in even gaps 0..6, a read in every odd gap).
@@ -103,10 +125,10 @@ __device__ __host__ constexpr EsTab es_make_tab() {
 #define AM_ES_CAP_FULL 8
 #endif
 #ifndef AM_ES_CAP_DMA
-#define AM_ES_CAP_DMA 3
+#define AM_ES_CAP_DMA 0
 #endif
 #ifndef AM_ES_CAP_READ
-#define AM_ES_CAP_READ 7
+#define AM_ES_CAP_READ 8
 #endif
 struct EsTab32 { int lo[33]; };
 __device__ __host__ constexpr int es_cap32(bool pv, int gap) {
@@ -114,37 +136,22 @@ __device__ __host__ constexpr int es_cap32(bool pv, int gap) {
   const bool rd = pv ? (gap & 7) < 4 : (gap & 1) == 1;
   return dma ? AM_ES_CAP_DMA : rd ? AM_ES_CAP_READ : AM_ES_CAP_FULL;
 }
-__device__ __host__ constexpr EsTab32 es_make_tab32(bool pv) {
+__device__ __host__ constexpr EsTab32 es_make_tab32(const EsSeq& q, bool pv) {
   int cum[33] = {};
   for (int i = 0; i < 32; ++i) cum[i + 1] = cum[i] + es_cap32(pv, i);
   EsTab32 t{};
   int n = 0;
   for (int i = 0; i <= 32; ++i) {        // steps whose cumulative cost starts below cum[i] / cum[32] of the total go before gap i
-    while (n < 80 && es_cost_before(n) * cum[32] < cum[i] * 112) ++n;
+    while (n < q.n && es_cost_before(q, n) * cum[32] < cum[i] * q.cost) ++n;
     t.lo[i] = n;
   }
-  t.lo[32] = 80;
-  return t;
-}
-
-#ifndef AM_LAZY_X1
-#define AM_LAZY_X1 0
-#endif
-#ifndef AM_LAZY_X2
-#define AM_LAZY_X2 0
-#endif
-#ifndef AM_LAZY_X3
-#define AM_LAZY_X3 0
-#endif
-__device__ __host__ constexpr EsTab32 es_tab32_late() {      // experiment: nothing in the first 8 gaps, the 24-gap table after
-  EsTab32 t{};
-  const EsTab o = es_make_tab();
-  for (int i = 0; i <= 32; ++i) t.lo[i] = i < 8 ? 0 : o.lo[i - 8];
+  t.lo[32] = q.n;
   return t;
 }
 
 template <int ABL>
-struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, skewed by one pair
+struct ExpSumPackT {
+  static constexpr EsSeq SEQ = es_make_seq();
   float rs[4];
   __device__ __forceinline__ void init() { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; }
   __device__ __forceinline__ static float get(const f32x16_t& sa, const f32x16_t& sb, int e) { return e < 16 ? sa[e] : sb[e - 16]; }
@@ -161,19 +168,10 @@ struct ExpSumPackT {       // 80 steps: 32 exp, 32 row-sum adds, 16 bf16 packs, 
     w[pr >> 2][pr & 3] = v;
   }
   __device__ __forceinline__ void step(int n, f32x16_t& sa, f32x16_t& sb, u32x4_t (&w)[4]) {
-    if (n < 2) { ex(sa, sb, n); return; }
-    if (n >= 77) {
-      if (n == 77) ad(sa, sb, 30);
-      else if (n == 78) ad(sa, sb, 31);
-      else pk(sa, sb, 15, w);
-      return;
-    }
-    const int r = (n - 2) / 5 + 1, k = (n - 2) % 5;     // round r = 1..15
-    if (k == 0) ex(sa, sb, 2 * r);
-    else if (k == 1) ex(sa, sb, 2 * r + 1);
-    else if (k == 2) ad(sa, sb, 2 * r - 2);
-    else if (k == 3) ad(sa, sb, 2 * r - 1);
-    else pk(sa, sb, r - 1, w);
+    const int k = SEQ.kind[n], a = SEQ.arg[n];
+    if (k == ES_EX) ex(sa, sb, a);
+    else if (k == ES_AD) ad(sa, sb, a);
+    else pk(sa, sb, a, w);
   }
   __device__ __forceinline__ float total() const { return (rs[0] + rs[1]) + (rs[2] + rs[3]); }
 };
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
     const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
     ExpSumPackT<ABL> es;
-    constexpr EsTab32 ES1 = AM_LAZY_X3 ? es_tab32_late() : es_make_tab32(true), ES2 = AM_LAZY_X2 ? es_tab32_late() : es_make_tab32(false);
+    constexpr EsTab32 ES1 = es_make_tab32(es.SEQ, true), ES2 = es_make_tab32(es.SEQ, false);
     auto bf = [](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
     // ===== phase 1: O += V^T(g-1) P^T(g-1) || softmax of block 0; K(g+3) DMA; K(g+1) prefetch =====
     stamp(g, 2);
@@ -445,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         FENCE();
       }
       HOLD4(vf[kk & 1][0], vf[kk & 1][1], vf[kk & 1][2], vf[kk & 1][3]);
+      if (kk == 0) stamp(g, 3);
     }
     stamp(g, 4);
     const float part0 = es.total();
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     uint64_t ok0 = __builtin_amdgcn_ballot_w64(part0 <= LAZY_T);    // evaluated here, branched on a phase later:
     asm volatile("" : "+s"(ok0));                                   // no VALU -> branch latency in the loop
     // block 1, previous tile: its P has just been consumed (O and l agree), S(g) is not exponentiated yet
-    if (!AM_LAZY_X1 && ok1_prev != ~0ull) lazy_rebase(1, part1_prev, nullptr, s1c);
+    if (ok1_prev != ~0ull) lazy_rebase(1, part1_prev, nullptr, s1c);
     // ===== phase 2: S(g+1) = K(g+1) Q^T || softmax of block 1; V^T(g+2) DMA; V^T(g) prefetch =====
     es.init();
     FENCE();
@@ -478,12 +477,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         FENCE();
       }
       HOLD2(kf[ks % 3][0], kf[ks % 3][1]);
+      if (ks == 1) stamp(g, 5);
     }
     stamp(g, 6);
     const float part1 = es.total();
     l_run[1] += part1;
     // block 0, this tile: P(g) is computed but not consumed, S(g+1) is accumulated
-    if (!AM_LAZY_X1 && ok0 != ~0ull) lazy_rebase(0, part0, &p0n, s0);
+    if (ok0 != ~0ull) lazy_rebase(0, part0, &p0n, s0);
     ok1_prev = __builtin_amdgcn_ballot_w64(part1 <= LAZY_T);
     part1_prev = part1;
     asm volatile("" : "+s"(ok1_prev));
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     RowMax rm;
     ExpSumPackT<ABL> es;
 
-    constexpr EsTab ES = es_make_tab();
+    constexpr EsTab ES = es_make_tab(es.SEQ);
     auto es_gap = [&](int gap, f32x16_t& sa, f32x16_t& sb, u32x4_t (&w)[4]) __attribute__((always_inline)) {
 #pragma unroll
       for (int n = ES.lo[gap]; n < ES.lo[gap + 1]; ++n) es.step(n, sa, sb, w);
@@ -800,19 +800,19 @@ static int launch64(const am_attn_args* a, int tiles_per_chunk, int nblk_main, v
 int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream) {
 #ifdef AM_ATTN_ABLATIONS
   switch (a->defer_log2) {     // 3000 + ABL: timing ablations (tools/kernel_bench.py --ablate64)
-    case 3001: return launch64<8, 1, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3002: return launch64<8, 2, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3004: return launch64<8, 4, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3008: return launch64<8, 8, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3010: return launch64<8, 10, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3014: return launch64<8, 14, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3016: return launch64<8, 16, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3030: return launch64<8, 30, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3032: return launch64<8, 32, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3064: return launch64<8, 64, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3128: return launch64<8, 128, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3132: return launch64<8, 132, 0>(a, tiles_per_chunk, nblk_main, stream);
-    case 3142: return launch64<8, 142, 0>(a, tiles_per_chunk, nblk_main, stream);
+    case 3001: return launch64<8, 1, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3002: return launch64<8, 2, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3004: return launch64<8, 4, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3008: return launch64<8, 8, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3010: return launch64<8, 10, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3014: return launch64<8, 14, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3016: return launch64<8, 16, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3030: return launch64<8, 30, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3032: return launch64<8, 32, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3064: return launch64<8, 64, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3128: return launch64<8, 128, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3132: return launch64<8, 132, 0, true>(a, tiles_per_chunk, nblk_main, stream);
+    case 3142: return launch64<8, 142, 0, true>(a, tiles_per_chunk, nblk_main, stream);
     default: break;
   }
 #endif
@@ -835,11 +835,20 @@ int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_mai
 #ifdef AM_ATTN_ABLATIONS
 // per-phase s_memtime stamps of workgroup (0,0): prof[4 waves][8 tiles (64..71)][8 slots]  (tools/attn_profile.py --k64)
 extern "C" int am_attention64_profile(const am_attn_args* a, unsigned long long* prof_dev, void* stream) {
-  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
+  const bool lazy = a->defer_log2 != 28;
+  const void* fn = lazy ? reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, true, 0, true>)
+                        : reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, true>);
+  AM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
-  hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, true>), dim3(ceil_div(a->sq, QBLK), a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
-                     (hipStream_t)stream, *a, tiles_per_chunk, prof_dev, (unsigned*)nullptr, 0);
+  const int nblk = ceil_div(a->sq, QBLK);
+  unsigned* flags = nullptr;
+  AM_TRY(lazy_flags((int64_t)nblk * a->nseq * a->heads, &flags));
+  if (lazy)
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, true, 0, true>), dim3(nblk, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
+                       (hipStream_t)stream, *a, tiles_per_chunk, prof_dev, flags, nblk);
+  else
+    hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, true>), dim3(nblk, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_B,
+                       (hipStream_t)stream, *a, tiles_per_chunk, prof_dev, (unsigned*)nullptr, 0);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

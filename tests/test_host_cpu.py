@@ -205,8 +205,6 @@ def test_attn64_register_audit(tmp_path):
             continue
         m = re.match(r"\s+([a-z]\S*)\s*(.*)", code)
         if not m:
-            if re.match(r"\S+:", code):
-                hot = {}                      # label: textual order is not execution order beyond this point
             continue
         op, args = m.group(1), m.group(2)
         step = int(args.strip()) + 1 if op == "s_nop" else 1

@@ -15,6 +15,8 @@ a.Q, a.K, a.Vt, a.O = Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr()
 a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = B, H, S, Q.shape[2], S, K.shape[2]
 a.nchunks = 1; a.chunk_stride = 0; a.ldo = H * 128; a.scale = 128 ** -0.5; a.defer_log2 = 8
 if "--k64" in sys.argv:
+    if "--exact" in sys.argv:
+        a.defer_log2 = 28
     prof = torch.zeros(4 * 8 * 8, dtype=torch.int64, device=dev)
     lib = C.CDLL(L.LIB_PATH)
     lib.am_attention64_profile.argtypes = [C.POINTER(L.AmAttnArgs), C.c_void_p, C.c_void_p]
@@ -23,8 +25,8 @@ if "--k64" in sys.argv:
     torch.cuda.synchronize()
     assert rc == 0
     p = prof.cpu().view(4, 8, 8)
-    print("4x64 kernel, workgroup (0,0), cycles (s_memtime): barrier | dma issue | 1a (8 PV + row max 0) | branch+1b (24 PV + exp 0) | "
-          "2a (8 QK + row max 1) | branch+2b (24 QK + exp 1) | loop tail")
+    print("4x64 kernel (lazy; --exact: exact re-base), workgroup (0,0), cycles (s_memtime): barrier | dma issue | 1a (first 8 PV, DMA) | "
+          "1b (24 PV) | 2a (first 8 QK, DMA) | 2b (24 QK) | loop tail")
     for w in range(4):
         print(f"wave {w}:")
         for t in range(0, 7):

@@ -7,12 +7,17 @@
 //     the overlap does not depend on how the SIMD arbitrates between two waves:
 //         phase 1(g):  O += V^T(g-1) P^T(g-1)   (32 MFMA)  ||  softmax of block 0 of tile g
 //         phase 2(g):  S(g+1) = K(g+1) Q^T      (32 MFMA)  ||  softmax of block 1 of tile g
-//     each phase = [8 MFMA || row max] -> rare rescale branch -> [24 MFMA || exp, row sum, bf16 pack];
-//   * the running max is folded into the MFMA: the score accumulators start at -m_run (a 16-register
-//     splat per block, rewritten only when a row's max grows past the deferred-rescale threshold), so
-//     scores are born as S - m_run and the per-element subtraction disappears.  Block 1's accumulators
-//     are initialised while its previous softmax may still move m_run; that offset is carried as a
-//     pending correction (`pend`), applied in the (rare) tile after a rescale;
+//   * -m_run is folded into the MFMA: the score accumulators start from a 16-register splat of -m_run per block
+//     (rewritten only on a re-base), so scores are born as S - m_run and the per-element subtraction disappears;
+//   * two forms of the online softmax (template parameter LAZY):
+//       exact  each phase = [8 MFMA || row max] -> rare re-base branch (deferred: threshold 2^8) -> [24 MFMA || exp,
+//              row sum, bf16 pack].  Block 1's accumulators are initialised while its previous softmax may still
+//              move m_run; that offset is carried as a pending correction (`pend1`), applied in the tile after;
+//       lazy   (product) no row max: m_run starts at 0 and moves up by whole octaves when a tile's row sums say it
+//              has fallen behind (> 2^12) - O, l and the pending P are multiplied by an exact power of two; each
+//              phase = 32 MFMA || the whole exp / row sum / pack of one block.  What it cannot represent marks the
+//              workgroup, and the exact kernel launched behind it over the same grid redoes the marked ones
+//              (comment at LAZY_T below);
 //   * K/V^T tiles (64 keys) live in a 4-deep LDS ring (128 KiB): in iteration g the MFMAs read V^T(g-1) and
 //     K(g+1); K is fetched three tiles ahead and V^T two (LDS-DMA pieces issued one per MFMA pair inside the two
 //     light phases, source = scalar base + 32-bit lane offset), one barrier per tile with a counted

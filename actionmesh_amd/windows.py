@@ -4,7 +4,11 @@ Mirrors, with the same names and semantics,
   * `chunk_right` / `chunk_left` / `chunk_from`  - actionmesh/model/utils/timesteps.py:10-117 (window index lists);
   * `LatentBank`                                 - actionmesh/model/utils/storage.py:89-186 (latents keyed by timestep);
   * `ActionMeshPipeline._denoise_latents` / `generate_3d_latents` - pipeline.py:247-314, 469-506 (one window of
-    flow-matching conditioned on the bank; the loop over windows).
+    flow-matching conditioned on the bank; the loop over windows);
+  * `get_scaling` / `apply_scaling` / `get_n_subdivisions` / `interpolate_timesteps` - model/utils/embeddings.py:156-245,
+    and the Stage-II window loop `ActionMeshPipeline.generate_mesh_animation` / `_decode_displacement`
+    (pipeline.py:316-385, 510-600) as `generate_vertex_animation`: the same loop on vertex tensors (the trimesh objects,
+    their vertex normals and the MeshBank stay with the caller - mesh glue of the reference's CPU path).
 MI355X-first differences: the bank is ONE device tensor (capacity x N x D) plus a host-side timestep -> slot table
 (video timesteps are host floats, pipeline io/video_input.py:34), so `get` is a single gather and `update` a single
 scatter instead of a Python loop of per-frame `.to(device)` / `torch.stack`; the masks the sampler needs are produced
@@ -141,6 +145,10 @@ class LatentBank:
             lat = lat * m.to(lat.dtype).view((-1,) + (1,) * len(self.empty_dims))
         return (lat[None], m[None]) if add_batch_dim else (lat, m)
 
+    def get_ordered_timesteps(self) -> torch.Tensor:
+        """All stored timesteps, ascending (storage.py:78-83)."""
+        return torch.tensor(sorted(self.timesteps))
+
     def get_ordered(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """All stored latents sorted by timestep, with the timesteps (storage.py:171-186)."""
         order = sorted(range(len(self.timesteps)), key=lambda i: self.timesteps[i])
@@ -189,3 +197,70 @@ def generate_3d_latents(denoiser, scheduler, cf_guidance, timesteps: torch.Tenso
                              device, noise_device, cb)
         bank.update(timesteps=ts, latents=lat)
     return bank
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Stage II window loop (embeddings.py:156-245; pipeline.py:316-385, 510-600)
+# ---------------------------------------------------------------------------------------------------------
+def get_scaling(timesteps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(B, T) -> per-row (min, max - min)."""
+    t_min = timesteps.min(dim=1).values
+    return t_min, timesteps.max(dim=1).values - t_min
+
+
+def apply_scaling(timesteps: torch.Tensor, t_min: torch.Tensor, t_range: torch.Tensor) -> torch.Tensor:
+    """(timesteps - t_min) / t_range for (B,) or (B, T) timesteps."""
+    if timesteps.dim() == 1:
+        return (timesteps - t_min) / t_range
+    return (timesteps - t_min.unsqueeze(1)) / t_range.unsqueeze(1)
+
+
+def get_n_subdivisions(start, end, level: int = 1) -> int:
+    """Points on [start, end] after `level - 1` midpoint subdivisions of the unit-spaced grid."""
+    n = int(end - start + 1)
+    for _ in range(1, level):
+        n += n - 1
+    return n
+
+
+def interpolate_timesteps(timesteps: torch.Tensor, subsampling_level: int, device=None, drop_first: bool = False) -> torch.Tensor:
+    """(1, n) linspace between the global min and max of `timesteps` (any shape), optionally without its first point."""
+    t_min, t_max = timesteps.min().item(), timesteps.max().item()
+    out = torch.linspace(t_min, t_max, get_n_subdivisions(t_min, t_max, level=subsampling_level), device=device).reshape(1, -1)
+    return out[:, 1:] if drop_first else out
+
+
+def generate_vertex_animation(autoencoder, latent_bank: LatentBank, vertex_bank: LatentBank,
+                              vertex_features: Callable[[torch.Tensor], torch.Tensor], anchor_idx: int, window: int, slide: int,
+                              subsampling_level: int = 1, device=None,
+                              step_callback: Optional[Callable[[int, int, int, int], None]] = None) -> LatentBank:
+    """`ActionMeshPipeline.generate_mesh_animation` on vertex tensors.
+
+    `latent_bank`: the Stage-I latents; `vertex_bank`: a LatentBank with empty_dims (V, 3) that already holds the anchor
+    mesh's vertices at the anchor timestep and receives every output timestep's deformed vertices (first write wins,
+    like the MeshBank); `vertex_features(vertices (V, 3)) -> (V, 3 + extra)`: positions + normalised vertex normals of
+    the window's source mesh (pipeline.py:351-354 via trimesh).  Windows grow outwards from the anchor (`chunk_from`);
+    the source mesh of a window is the one stored for its first timestep."""
+    device = autoencoder.device if device is None else torch.device(device)
+    windows = chunk_from(start=anchor_idx, total=latent_bank.n_timesteps, size=window, slide=slide)
+    all_timesteps = latent_bank.get_ordered_timesteps()
+    for i, idx in enumerate(windows):
+        window_timesteps = all_timesteps[idx][None]
+        latents, _ = latent_bank.get(window_timesteps[0], device=device, add_batch_dim=True)
+        source, have = vertex_bank.get(window_timesteps[0, :1], device=device)
+        if int(have[0]) != 1:
+            raise RuntimeError(f"generate_vertex_animation: no mesh stored for timestep {float(window_timesteps[0, 0])}")
+        output_timesteps = interpolate_timesteps(window_timesteps, subsampling_level, drop_first=True)
+        t_min, t_range = get_scaling(window_timesteps)
+        source_alpha = apply_scaling(window_timesteps[:, 0], t_min, t_range)
+        target_alphas = apply_scaling(output_timesteps, t_min, t_range)
+        cb = None
+        if step_callback is not None:
+            def cb(step, total, _i=i, _n=len(windows)):
+                step_callback(step, total, _i, _n)
+        feats = vertex_features(source[0])[None].to(device)
+        disp = autoencoder(latent=latents, framestep=window_timesteps, source_alpha=source_alpha, target_alphas=target_alphas,
+                           query=feats, step_callback=cb)
+        deformed = autoencoder.apply_displacement(vertex=feats[..., :3], displacement=disp)
+        vertex_bank.update(timesteps=output_timesteps[0], latents=deformed[0])
+    return vertex_bank

@@ -9,6 +9,8 @@ Pins (the callers of the Stage-I hot path):
     (start, total, size, slide), including the shipped (size 16, slide 15) setting;
   * actionmesh/model/utils/storage.py: LatentBank.update / get / get_ordered semantics (first write wins unless
     replace=True, eps-matching of float timesteps, zero latents + mask 0 for missing timesteps).
+  * actionmesh/model/utils/embeddings.py: get_scaling / apply_scaling / get_n_subdivisions / interpolate_timesteps, the
+    timestep arithmetic of the Stage-II window loop (pipeline.py:553-566).
 `trimesh` (imported by storage.py for the MeshBank) is not installed offline: an empty stand-in module is registered.
 """
 import json
@@ -25,6 +27,8 @@ if "trimesh" not in sys.modules:
     tm.Trimesh = type("Trimesh", (), {})
     sys.modules["trimesh"] = tm
 
+from actionmesh.model.utils.embeddings import (apply_scaling, get_n_subdivisions, get_scaling,  # noqa: E402  (reference)
+                                               interpolate_timesteps)
 from actionmesh.model.utils.storage import LatentBank  # noqa: E402  (reference)
 from actionmesh.model.utils.timesteps import chunk_from, chunk_left, chunk_right  # noqa: E402
 
@@ -65,6 +69,20 @@ for op in script:
     else:
         lat, ts = bank.get_ordered()
         out["bank"].append({"op": "ordered", "latents": lat.tolist(), "timesteps": ts.tolist()})
+
+# Stage-II timestep arithmetic: what pipeline.py:553-566 computes for a window of (possibly unordered) timesteps
+out["scaling"] = []
+for ts in ([0.0, 1.0, 2.0, 3.0], [5.0, 4.0, 3.0, 2.0, 1.0, 0.0], [7.0, 3.0, 4.0, 5.0, 6.0], [0.0, 2.0, 4.0, 6.0],
+           [list(range(16))][0], [15.0] + [float(v) for v in range(15)], [10.0, 11.0], [2.5, 3.5, 4.5]):
+    w = torch.tensor([[float(v) for v in ts]])
+    for level in (1, 2, 3):
+        o = interpolate_timesteps(w, subsampling_level=level, device="cpu", drop_first=True)
+        o_all = interpolate_timesteps(w, subsampling_level=level, device="cpu", drop_first=False)
+        t_min, t_range = get_scaling(w)
+        out["scaling"].append({"timesteps": w[0].tolist(), "level": level, "n": get_n_subdivisions(w.min().item(), w.max().item(), level),
+                               "output": o[0].tolist(), "output_all": o_all[0].tolist(), "t_min": t_min.tolist(),
+                               "t_range": t_range.tolist(), "source_alpha": apply_scaling(w[:, 0], t_min, t_range).tolist(),
+                               "target_alphas": apply_scaling(o, t_min, t_range)[0].tolist()})
 
 path = os.path.join(ROOT, "tests", "golden", "windows.json")
 with open(path, "w") as f:

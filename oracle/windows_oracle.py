@@ -103,3 +103,29 @@ def generate_3d_latents(sd, cfg: O.OracleConfig, timesteps: torch.Tensor, contex
                             num_inference_steps, precision=precision)[-1]
         bank.update(ts, lat)
     return bank
+
+
+def generate_mesh_animation(decode, latent_bank: ListLatentBank, meshes: dict, anchor_idx: int, window: int, slide: int,
+                            subsampling_level: int = 1) -> dict:
+    """pipeline.py:510-600 with the meshes reduced to their vertex tensors: `meshes` maps a timestep to (V, 3) vertices
+    and already holds the anchor's; `decode(latents (1, T, N, D), window_timesteps (1, T), source_alpha (1,),
+    target_alphas (1, T_out), source_vertices (V, 3)) -> (T_out, V, 3)` stands for `_decode_displacement`
+    (pipeline.py:316-385).  Timestep arithmetic as in embeddings.py:156-245, written out with Python floats."""
+    ordered = sorted(latent_bank.timesteps)
+    for idx in chunk_from(anchor_idx, len(ordered), window, slide):
+        wts = [ordered[int(i)] for i in idx]
+        latents, _ = latent_bank.get(torch.tensor(wts), add_batch_dim=True)
+        src = next(v for t, v in meshes.items() if abs(t - wts[0]) < 1e-5)          # MeshBank.get(window_timesteps[:, 0])
+        t_min, t_max = min(wts), max(wts)
+        n = int(t_max - t_min + 1)
+        for _ in range(1, subsampling_level):
+            n += n - 1
+        out_ts = torch.linspace(t_min, t_max, n)[1:]                               # drop_first=True
+        rng = t_max - t_min
+        source_alpha = torch.tensor([(wts[0] - t_min) / rng])
+        target_alphas = ((out_ts - t_min) / rng)[None]
+        verts = decode(latents, torch.tensor([wts]), source_alpha, target_alphas, src)
+        for t, v in zip(out_ts.tolist(), verts):
+            if not any(abs(t - k) < 1e-5 for k in meshes):                          # first write wins
+                meshes[t] = v
+    return meshes

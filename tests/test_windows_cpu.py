@@ -113,3 +113,78 @@ def test_generate_3d_latents_drives_sampler_like_the_reference():
     assert bank.n_timesteps == T and seen == [(i, len(want)) for i in range(len(want))]
     lat, m = bank.get(ts[3:4])
     assert float(lat[0, 0, 0]) == 7.0, "the anchor latent is never overwritten (first write wins)"
+
+
+# ---- Stage-II window loop (pipeline.py:510-600) ----------------------------------------------------------------
+def test_timestep_scaling_matches_reference(gold):
+    """get_scaling / apply_scaling / get_n_subdivisions / interpolate_timesteps against values computed by the reference's
+    own functions (embeddings.py:156-245) for ordered, reversed and anchor-first windows and three subsampling levels."""
+    from actionmesh_amd import windows as W
+    assert len(gold["scaling"]) >= 20
+    for c in gold["scaling"]:
+        w = torch.tensor([c["timesteps"]])
+        assert W.get_n_subdivisions(w.min().item(), w.max().item(), c["level"]) == c["n"]
+        assert W.interpolate_timesteps(w, c["level"], drop_first=True)[0].tolist() == c["output"]
+        assert W.interpolate_timesteps(w, c["level"], drop_first=False)[0].tolist() == c["output_all"]
+        t_min, t_range = W.get_scaling(w)
+        assert t_min.tolist() == c["t_min"] and t_range.tolist() == c["t_range"]
+        assert W.apply_scaling(w[:, 0], t_min, t_range).tolist() == c["source_alpha"]
+        assert W.apply_scaling(W.interpolate_timesteps(w, c["level"], drop_first=True), t_min, t_range)[0].tolist() == c["target_alphas"]
+
+
+class _RecordingAutoencoder:
+    """Stands for the decoder: displacement = a deterministic function of everything it is handed, so that a wrong
+    window, source mesh, alpha or latent shows up in the stored vertices."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.calls = []
+
+    def __call__(self, latent, framestep, source_alpha, target_alphas, query, step_callback=None):
+        self.calls.append((framestep.tolist(), source_alpha.tolist(), target_alphas.tolist()))
+        T_out = target_alphas.shape[1]
+        if step_callback is not None:
+            for i in range(T_out):
+                step_callback(i + 1, T_out)
+        base = query[0, :, :3] * 0.5 + latent.mean() + framestep.sum() * 1e-3
+        return torch.stack([base + 0.01 * float(a) - float(source_alpha[0]) for a in target_alphas[0]])[None]
+
+    @staticmethod
+    def apply_displacement(vertex, displacement, scale=1.0):
+        return torch.clamp(displacement, -scale, scale)
+
+
+@pytest.mark.parametrize("n_frames,anchor,level", [(16, 0, 1), (31, 0, 1), (31, 12, 1), (20, 19, 2), (7, 0, 1)])
+def test_generate_vertex_animation_matches_the_restated_reference_loop(n_frames, anchor, level):
+    from actionmesh_amd import windows as W
+    from oracle import windows_oracle as WO
+    g = torch.Generator().manual_seed(n_frames * 100 + anchor)
+    N, D, V, size, slide = 5, 4, 9, 16, 15
+    ts = torch.arange(n_frames, dtype=torch.float32)
+    lat = torch.randn((n_frames, N, D), generator=g)
+    verts = torch.rand((V, 3), generator=g) - 0.5
+    feats = lambda v: torch.cat([v, torch.nn.functional.normalize(v + 0.1, dim=-1)], -1)
+    ae = _RecordingAutoencoder()
+    bank = W.LatentBank(empty_dims=(N, D)); bank.update(ts, lat)
+    vbank = W.LatentBank(empty_dims=(V, 3)); vbank.update(ts[anchor:anchor + 1], verts[None])
+    seen = []
+    W.generate_vertex_animation(ae, bank, vbank, feats, anchor, size, slide, subsampling_level=level,
+                                step_callback=lambda s, t, i, n: seen.append((s, t, i, n)))
+    obank = WO.ListLatentBank(empty_dims=(N, D)); obank.update(ts, lat)
+    ae2 = _RecordingAutoencoder()
+
+    def decode(latents, wts, sa, ta, src):
+        d = ae2(latents, wts, sa, ta, feats(src)[None])
+        return ae2.apply_displacement(None, d)[0]
+    meshes = WO.generate_mesh_animation(decode, obank, {float(anchor): verts}, anchor, size, slide, subsampling_level=level)
+    assert ae.calls == ae2.calls and len(ae.calls) == len(W.chunk_from(anchor, n_frames, size, slide))
+    got, got_ts = vbank.get_ordered()
+    assert got_ts.tolist() == sorted(meshes)
+    for t, v in zip(got_ts.tolist(), got):
+        assert torch.equal(v, meshes[t]), t
+    assert {(i, n) for _, _, i, n in seen} == {(i, len(ae.calls)) for i in range(len(ae.calls))}
+    if level == 1 and anchor == 0:
+        assert got_ts.tolist() == ts.tolist()          # every input frame gets a mesh, the anchor keeps its own
+        assert torch.equal(got[anchor], verts)
+    # (with a later anchor the reference's drop_first removes the window's MINIMUM timestep, not its source frame - a
+    #  descending window never decodes frame 0; mirrored as is, see the oracle restatement)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python
+"""GPU part of the video -> 4D pipeline, end to end on synthetic data, one MI355X:
+
+    frames (T x 3 x 224 x 224)  --HipImageEncoder (DINOv2 ViT-L/14)-->  context (T, 257, 1024)
+    anchor latent + context     --generate_3d_latents (Stage I: AR windows of 16 frames, flow matching, CFG)-->  latents
+    latents + anchor vertices   --generate_vertex_animation (Stage II: ActionMeshAutoencoder per window)-->  vertices per frame
+
+at the shipped shapes (Stage I: N = 2048 tokens, width 2048, 16 heads, 21 layers; Stage II: width 1024, 16 + 1 blocks) with
+random-init weights.  What stays on the reference's CPU path (and is not timed here): background removal, TripoSG
+Stage 0, mesh post-processing / vertex normals (trimesh), GLB export.  Prints one JSON line (secondary metric:
+BASELINE.json's "end-to-end video->4D wall-clock" restricted to the stages this repository implements).
+
+    python tools/e2e_synthetic.py [--frames 16] [--steps 30] [--vertices 50000] [--tiny]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rand_like_spec(shapes, g):
+    sd = {}
+    for name, shape in shapes.items():
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            sd[name] = torch.randn(shape, generator=g) / fan ** 0.5
+        elif name.endswith(".weight") or name.endswith("lambda1"):
+            sd[name] = torch.ones(shape)
+        elif name.startswith("embeddings.") and not name.endswith(".bias"):
+            sd[name] = 0.5 * torch.randn(shape, generator=g)
+        else:
+            sd[name] = torch.zeros(shape)
+    return sd
+
+
+def build(tiny: bool, dev):
+    from bench import random_state_dict
+    from actionmesh_amd import ClassifierFreeGuidance, HipAutoencoder, HipDenoiser, HipImageEncoder, HipSchedulerFlow
+    from actionmesh_amd import image_encoder as IE
+    g = torch.Generator().manual_seed(0)
+    if tiny:
+        dino = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=56)
+        den = dict(in_channels=64, num_layers=3, num_attention_heads=2, width=256, mlp_ratio=4.0, cross_attention_dim=128,
+                   inflated_layers=[0, 1, 2])
+        ae = dict(width=256, num_layers=2, num_attention_heads=2, latent_channels=64)
+        n_tokens, window, side = 40, 4, 56
+    else:
+        dino = {}
+        den = dict(in_channels=64, num_layers=21, num_attention_heads=16, width=2048, mlp_ratio=4.0, cross_attention_dim=1024,
+                   inflated_layers=list(range(21)))
+        ae = dict(width=1024, num_layers=16, num_attention_heads=8, latent_channels=64)
+        n_tokens, window, side = 2048, 16, 224
+    enc = HipImageEncoder(config=dino, state_dict=rand_like_spec(IE.state_dict_shapes(dict(IE._CFG_DEFAULTS, **dino)), g)).to(dev)
+    denoiser = HipDenoiser(num_tokens_nominal=n_tokens, temporal_context_size=window, **den)
+    denoiser.load_state_dict(random_state_dict(den, seed=0))
+    denoiser.to(dev).eval()
+    from oracle.autoencoder_oracle import AEConfig, state_dict_spec      # parameter names / shapes only
+    vae = HipAutoencoder(temporal_context_size=window, **ae)
+    vae.load_state_dict(rand_like_spec(dict(state_dict_spec(AEConfig(**ae))), g))
+    vae.to(dev)
+    return enc, denoiser, vae, HipSchedulerFlow, ClassifierFreeGuidance, n_tokens, window, side
+
+
+def run(frames: int, steps: int, vertices: int, tiny: bool, dev, seed: int = 44):
+    from actionmesh_amd import LatentBank, generate_3d_latents, generate_vertex_animation
+    t_build = time.perf_counter()
+    enc, denoiser, vae, Sched, CFG, n_tokens, window, side = build(tiny, dev)
+    torch.cuda.synchronize(dev)
+    t_build = time.perf_counter() - t_build
+    g = torch.Generator().manual_seed(1)
+    pixels = torch.randn((frames, 3, side, side), generator=g).to(dev)
+    timesteps = torch.arange(frames, dtype=torch.float32)
+    anchor_latent = torch.randn((1, n_tokens, 64), generator=g).to(dev)
+    pts = torch.nn.functional.normalize(torch.randn((vertices, 3), generator=g), dim=-1) * 0.8        # a sphere of radius 0.8
+    features = lambda v: torch.cat([v, torch.nn.functional.normalize(v, dim=-1)], dim=-1)              # its normals
+    sched, cfg = Sched(num_inference_steps=steps, shift=3.0, is_additive=True), CFG(True, [[0, 1], [1, 1]], [7.5])
+    slide = window - 1
+
+    def stage(fn):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize(dev)
+        return out, time.perf_counter() - t0
+
+    context, t_enc = stage(lambda: enc.encode_pixels(pixels))
+    bank = LatentBank(empty_dims=(n_tokens, 64), device=str(dev))
+    bank.update(timesteps[:1], anchor_latent)
+    bank, t_s1 = stage(lambda: generate_3d_latents(denoiser, sched, cfg, timesteps, context, bank, 0, window, slide,
+                                                   (n_tokens, 64), seed=seed, device=dev))
+    vbank = LatentBank(empty_dims=(vertices, 3), device=str(dev))
+    vbank.update(timesteps[:1], pts[None].to(dev))
+    vbank, t_s2 = stage(lambda: generate_vertex_animation(vae, bank, vbank, features, 0, window, slide, device=dev))
+    verts, ts = vbank.get_ordered()
+    assert ts.tolist() == timesteps.tolist() and verts.shape == (frames, vertices, 3)
+    assert bool(torch.isfinite(verts).all()) and float(verts.abs().max()) <= 1.0
+    lat, _ = bank.get_ordered()
+    assert bool(torch.isfinite(lat).all())
+    n_win = len(__import__("actionmesh_amd").chunk_from(0, frames, window, slide))
+    return {"metric": "video->4D wall-clock, GPU stages (context encoder + Stage I + Stage II)", "value": round(t_enc + t_s1 + t_s2, 3),
+            "unit": "s", "higher_is_better": False, "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
+            "seconds": {"context_encoder": round(t_enc, 4), "stage_I": round(t_s1, 3), "stage_II": round(t_s2, 3),
+                        "model_build_and_upload": round(t_build, 1)},
+            "config": {"workload": f"{frames} frames, {n_win} AR window(s) of {window}, {steps} denoise steps, N={n_tokens} tokens, "
+                                   f"{vertices} vertices, {'tiny' if tiny else 'shipped'} model shapes, random-init weights"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--vertices", type=int, default=50000)
+    ap.add_argument("--tiny", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    print(json.dumps(run(a.frames, a.steps, a.vertices, a.tiny, dev)))
+
+
+if __name__ == "__main__":
+    main()

@@ -271,13 +271,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wp[j] + k0), (lds_ptr_t)(bbase + (j * 512 + wave * 64) * 16), 16, 0, 0);
   };
 
+  // accumulators start from the bias (fp32, in the MFMA layout: lane (l31, hi) holds columns 8g + 4hi .. +3 of block j)
   f32x16_t acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int g = 0; g < 4; ++g) {
+      f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + wn * 64 + j * 32 + 8 * g + 4 * hi, p.N - 4));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = bv[e];
+    }
 
   // fragment byte offsets inside a tile: row R, k-unit c -> (R*8 + (c ^ ((R>>1)&7))) * 16
   int a_row_off[4], a_sw[4], b_row_off[2], b_sw[2];
@@ -329,43 +335,71 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nl = wn * 64 + j * 32 + 8 * g + 4 * hi;          // 4 consecutive columns
-      f32x4_t bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + nl, p.N - 4));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ml = wm * 128 + i * 32 + l31;
-        float v[4];
+        u32x2_t w;
+        if (p.act == 1) {                                        // F.gelu on the bf16 linear output -> bf16
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rbf(acc[i][j][4 * g + e] + bv[e]);
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(acc[i][j][4 * g + e]));
+          w = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        } else {
+          w = u32x2_t{pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])};
         }
-        u32x2_t w = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
         const int u = (nl >> 2) ^ (ml & 15);
         *reinterpret_cast<u32x2_t*>(stage + ml * 512 + u * 8) = w;
       }
     }
   __syncthreads();
   {
-    const int k16 = tid & 31;                 // 16-byte chunk (8 columns) of the row
+    // thread -> 16-byte chunk k16 (8 columns) of rows ml = pass * 16 + (tid >> 5).  (ml & 15) does not depend on the pass,
+    // so the chunk sits at a fixed offset of its row and every per-pass LDS address is base + constant.
+    const int k16 = tid & 31, r16 = tid >> 5;
     const int gn = n0 + k16 * 8;
     if (gn < p.N) {
-#pragma unroll 4
-      for (int pass = 0; pass < 16; ++pass) {
-        const int ml = pass * 16 + (tid >> 5);
-        const int gmr = m0 + ml;
-        if (gmr < p.M) {
-          const int jj = k16 ^ ((ml & 15) >> 1);
-          u32x4_t sv = *reinterpret_cast<const u32x4_t*>(stage + ml * 512 + jj * 16);
-          if (ml & 1) sv = u32x4_t{sv[2], sv[3], sv[0], sv[1]};
-          const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
-          if (p.residual) {
-            const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(p.residual + pr * p.ldc + gn);
+      // the chunk's two 8-byte units; row r16 of each 16-row pass, +8192 B per pass
+      const unsigned char* su = stage + r16 * 512 + ((k16 ^ (r16 >> 1)) << 4);
+      const bool odd = r16 & 1;
+      auto fetch = [&](int pass) __attribute__((always_inline)) {
+        u32x4_t sv = *reinterpret_cast<const u32x4_t*>(su + pass * 8192);
+        if (odd) sv = u32x4_t{sv[2], sv[3], sv[0], sv[1]};
+        return sv;
+      };
+      auto add_res = [&](u32x4_t sv, const bf16_t* rp) __attribute__((always_inline)) {
+        const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(rp);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
+        for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
+        return sv;
+      };
+      if (p.c_G <= 0 && m0 + B2 <= p.M) {
+        // identity row map, full tile (every tile of the main grid at the reference shapes): rows advance by 16 * ldc per
+        // pass - wave-uniform base + one per-lane 32-bit offset, no per-pass address arithmetic, no bounds checks
+        const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
+        const int64_t step = (int64_t)16 * p.ldc;
+        bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
+        if (p.residual) {
+          const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
+#pragma unroll 4
+          for (int pass = 0; pass < 16; ++pass) {
+            const u32x4_t sv = add_res(fetch(pass), reinterpret_cast<const bf16_t*>(reinterpret_cast<const unsigned char*>(rrow + pass * step) + lane_off));
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = sv;
           }
-          *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = sv;
+        } else {
+#pragma unroll 4
+          for (int pass = 0; pass < 16; ++pass)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = fetch(pass);
+        }
+      } else {
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+          const int gmr = m0 + pass * 16 + r16;
+          if (gmr < p.M) {
+            u32x4_t sv = fetch(pass);
+            const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
+            if (p.residual) sv = add_res(sv, p.residual + pr * p.ldc + gn);
+            *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = sv;
+          }
         }
       }
     }

@@ -186,7 +186,7 @@ struct ExpSumPackT {
 // STATE (two-pass attention, am_attn_args.state_mode): 0 = one pass; 1 = save the un-normalised (O, m, l) of every row
 // to p.state instead of writing O; 2 = resume from p.state, finish, write O.
 constexpr int STATE_LD = 132;      // floats per saved row: O[128], m, l, pad (16-byte aligned rows)
-// LAZY: no row max at all.  m_run starts at 0 (scores in log2 units); the scores of a tile are exponentiated relative to the
+// LAZY: no row max in the loop.  m_run starts at tile 0's row max rounded up to a whole octave; the scores of a tile are exponentiated relative to the
 // m_run they were born with; the tile's row sums (computed anyway) tell afterwards whether m_run has fallen behind
 // (sum > 2^12), and the rare re-base multiplies O, l and the not yet consumed P by an exact power of two and moves m_run up
 // by that many octaves.  fp32 and bf16 share an 8-bit exponent, so a lag of up to 2^60 loses nothing.  What this cannot
@@ -366,6 +366,26 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
     for (int d = 0; d < 4; ++d) vf[0][d] = v_frag(smem + 3 * STAGE_B, d, 0);
     asm volatile("" :: "v"(negm[0]), "v"(negm[1]));     // SrcC of the first k-step stays allocated until here
+    if (LAZY && STATE != 2) {
+      // m_run starts at the exact row max of tile 0 rounded up to a whole octave (when resuming it comes from the saved
+      // state): un-normalised q.k (Stage II has no qk-norm) may sit tens of octaves away from 0, and a start that far off
+      // would send every workgroup through the exact fallback.
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1c[0]), "+v"(s1c[1]));   // MFMA results landed
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16_t& sa = j == 0 ? s0[0] : s1c[0];
+        f32x16_t& sb = j == 0 ? s0[1] : s1c[1];
+        RowMax rm;
+#pragma unroll
+        for (int n = 0; n < 20; ++n) rm.step(n, sa, sb);
+        const float m0 = __builtin_ceilf(rm.mx);
+        m_run[j] = m0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] -= m0; sb[r] -= m0; negm[j][r] = -m0; }
+        FENCE();
+      }
+      PIN(negm[0]); PIN(negm[1]);
+    }
   };
   bool poison = false;
   uint64_t ok1_prev = ~0ull;
@@ -693,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   for (int j = 0; j < 2; ++j) {
     float l = l_run[j] - (float)(cnt * p.nchunks) * __builtin_amdgcn_exp2f(-m_run[j]);
     l += __shfl_xor(l, 32);
-    // LAZY: m_run starts at 0 (or at the saved state's) and only ever moves up by whole octaves when a row sum says so.
+    // LAZY: m_run starts at tile 0's max (or at the saved state's) and only ever moves up by whole octaves when a row sum says so.
     // A row whose scores all sit far below it has lost its sum to underflow: let the exact kernel redo the workgroup.
     if (LAZY) poison |= !(l >= 0x1p-100f && l < 0x1p100f);
     const int q = q0 + 32 * j + l31;

@@ -362,6 +362,24 @@ def test_attention_lazy_rebase_and_exact_fallback(dev):
         ops.attention(Q, K, Vt, sq, skc, out=out, nchunks=2, rows=2)
         assert (out.float() - ref).abs().max().item() < 3e-2, f"rank {r}"
     assert ops.attention_fallback_count() == n1 + 2
+    # (e) un-normalised operands (Stage II has no qk-norm): scores tens of octaves away from 0 everywhere.  m_run starts at
+    #     tile 0's row max, so this is ordinary work for the lazy kernel, not a job for the fallback
+    qs = q * 4.0
+    ks_ = _randn((nseq, H, sk, 128), 5, dev) * 4.0
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (qs, ks_, v))
+    Q, K, Vt, skc = _layout(qb, kb, vb, 1)
+    smax = ((qb.float() @ kb.float().transpose(-1, -2)) * (128 ** -0.5) * 1.4427).amax(-1)
+    assert float(smax.min()) > 25.0 and float(smax.max()) > 60.0, (float(smax.min()), float(smax.max()))   # log2 units
+    out = ops.attention(Q, K, Vt, sq, skc).float()
+    exact = ops.attention(Q, K, Vt, sq, skc, defer_log2=28).float()
+    ref = _sdpa_ref(qb, kb, vb).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+    # scores of +-80 octaves amplify the bf16 rounding of the pre-scaled Q fragments (both kernel forms share it): the two
+    # forms must agree tightly, the fp32 softmax of the unscaled bf16 operands only loosely
+    assert (out - exact).abs().max().item() < 4e-2          # one bf16 ulp at |o| in [4, 8)
+    assert (out - ref).abs().max().item() < 0.3 and (exact - ref).abs().max().item() < 0.3
+    # of the 4 workgroups at most one meets a row whose later tiles top tile 0's max by more than 60 octaves (scores have a
+    # standard deviation of 23 octaves here); from m_run = 0 all four would have gone to the fallback
+    assert ops.attention_fallback_count() <= n1 + 2 + 1
 
 
 def test_attention_properties_full_size(dev):

@@ -256,19 +256,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
     const int wr = min(n0 + r, p.N - 1);
     wp[j] = p.W + (int64_t)wr * p.ldw + c * 8;
   }
-  auto dma_tile = [&](int kt, int buf) {
+  // piece j of the A tile and piece j of the W tile of k-tile kt
+  auto dma_pair = [&](int kt, int buf, int j) __attribute__((always_inline)) {
     const int k0 = kt * BK;
-    const bool first = k0 < p.K1;
     unsigned char* abase = smem + buf * 2 * T2_BYTES;
     unsigned char* bbase = abase + T2_BYTES;
+    const bf16_t* src = k0 < p.K1 ? a1p[j] + k0 : a2p[j] + k0;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(abase + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wp[j] + k0), (lds_ptr_t)(bbase + (j * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+  auto dma_tile = [&](int kt, int buf) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bf16_t* src = first ? a1p[j] + k0 : a2p[j] + k0;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(abase + (j * 512 + wave * 64) * 16), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wp[j] + k0), (lds_ptr_t)(bbase + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    for (int j = 0; j < 4; ++j) dma_pair(kt, buf, j);
   };
 
   // accumulators start from the bias (fp32, in the MFMA layout: lane (l31, hi) holds columns 8g + 4hi .. +3 of block j)
@@ -305,11 +304,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
   dma_drain_barrier();               // tile 0 landed and is visible
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) dma_tile(kt + 1, buf ^ 1);
+    // the next tile's 8 LDS-DMA pieces go out in two groups, in front of k-steps 0 and 1 (half a trip is left for them to
+    // land): issued back to back at the top of the trip, the 64 pieces of the 8 waves queue on the one TA and the waves
+    // sit in the issue of their pieces
+    const int kn = min(kt + 1, nk - 1);        // last trip: re-fetch the last tile into the idle buffer (drained below)
     const unsigned char* At = smem + buf * 2 * T2_BYTES;
     const unsigned char* Bt = At + T2_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
+      if (ks < 2) {
+        dma_pair(kn, buf ^ 1, 2 * ks);
+        dma_pair(kn, buf ^ 1, 2 * ks + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const int c = ks * 2 + hi;
       bf16x8_t af[4], bfr[2];
 #pragma unroll

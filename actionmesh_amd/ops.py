@@ -48,7 +48,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, gelu: bool = False,
          a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
-         M: Optional[int] = None, force_small: bool = False) -> torch.Tensor:
+         M: Optional[int] = None, force_small: bool = False, use_4wave: bool = False) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
@@ -75,7 +75,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.residual = _p(_need(residual, torch.bfloat16, "residual")) if residual is not None else None
     g.C = out.data_ptr(); g.ldc = out.stride(0)
     g.M, g.N, g.K = M, N, K
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0)   # 0x100: force the 128x128 kernel (A/B)
+    # 0x100: force the 128x128 kernel; 0x200: the hand-placed 4-wave main loop instead of the 8-wave 256x256 kernel (A/B)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if use_4wave else 0)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
     L.check(L.lib().am_gemm_bf16(C.byref(g), _stream()), "am_gemm_bf16")

@@ -214,3 +214,33 @@ def test_attn64_register_audit(tmp_path):
         hot = {k: v - step for k, v in hot.items() if v - step > 0}
         if in_asm and op.startswith("v_mfma") and args.split(",")[0].strip().startswith("v"):
             hot.update({r: 14 for r in vregs(args.split(",")[0])})
+
+
+def test_gemm4w_register_audit(tmp_path):
+    """The 4-wave GEMM main loop (am_gemm4w.hip) names all 256 AccVGPRs literally in inline asm: hipcc must not generate
+    a single AccVGPR access of its own in that kernel, and must not spill."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "actionmesh_amd", "csrc", "am_gemm4w.hip")
+    out = tmp_path / "g4.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-I", os.path.join(root, "include"),
+                    "-S", "-o", str(out), src], check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    assert re.search(r"\.agpr_count:\s+256", text) and re.search(r"\.private_segment_fixed_size:\s+0\b", text)
+    in_asm, n_mfma = False, 0
+    for ln in text.splitlines():
+        code = ln.split(";")[0]
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        elif in_asm and "v_mfma" in code:
+            n_mfma += 1
+        elif not in_asm and re.match(r"\s+(v_|ds_|global_|buffer_|scratch_|flat_)", code):
+            assert not re.search(r"\ba\[\d+:\d+\]|\ba\d+\b", code), f"compiler-generated AccVGPR access: {ln.strip()}"
+    assert n_mfma >= 32
+

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void k(const unsigned char* __restrict__ sr
   u32x4_t stg[2][4] = {};
   for (int it = 0; it < iters; ++it) {
     if (DMA == 104) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(DMA == 2 ? WAITN / 2 : DMA == 16 ? 32 : WAITN) : "memory");
+    else if (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(DMA == 2 || DMA == 3 ? WAITN / 2 : DMA == 16 ? 32 : WAITN) : "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void k(const unsigned char* __restrict__ sr
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + o3 + lane * 4), (lds_ptr_t)(smem + (piece & 127) * 256 + wave * 32768), 4, 0, 0);
           ++piece;
         }
-        if (DMA && DMA < 16 && n >= 8 && (DMA == 2 ? (n & 3) == 0 : (n & 1) == 0)) {
+        if (DMA == 3 ? (n & 7) == 2 * wave : DMA && DMA < 16 && n >= 8 && (DMA == 2 ? (n & 3) == 0 : (n & 1) == 0)) {   // 3: 2 pieces, waves staggered
           const size_t off = (pos + (size_t)(piece & 63) * 1024 + (size_t)wave * 16384) % (STREAM ? src_bytes : (size_t)src_bytes);
           // SKEW: every workgroup's window starts at a different offset inside the 4 KiB / 64 KiB address-interleave periods
           const size_t o2 = STREAM ? off : ((size_t)blockIdx.x * (65536 + SKEW) + ((size_t)((piece + (SKEW ? blockIdx.x * 5 : 0)) & 15) * 1024 + (size_t)wave * 16384)) % (src_bytes - 65536);
@@ -133,6 +133,7 @@ int main() {
   run<8, 4, false, false>("32x32x16  + 8 reads + 4 DMA (L2 window)", src, bytes, out);
   run<8, 4, false, true>("32x32x16  + 8 reads + 4 DMA (streamed from HBM)", src, bytes, out);
   run<8, 2, false, false>("32x32x16  + 8 reads + 2 DMA pieces / 16 MFMA (the attention kernel's ratio, L2)", src, bytes, out);
+  run<8, 3, false, false>("32x32x16  + 8 reads + 2 DMA pieces / 16 MFMA, the four waves staggered by 2 MFMAs (L2)", src, bytes, out);
   run<8, 2, false, true>("32x32x16  + 8 reads + 2 DMA pieces / 16 MFMA (HBM stream)", src, bytes, out);
   run<8, 16, false, false>("32x32x16  + 8 reads + 16 DMA pieces of 4 B/lane / 16 MFMA (same bytes, L2)", src, bytes, out);
   run<8, 4, false, false, 0>("32x32x16  + 8 reads + 4 DMA (L2), <= 8 pieces in flight per wave", src, bytes, out);

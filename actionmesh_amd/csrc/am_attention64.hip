@@ -394,9 +394,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   // w = a P tile that has been computed but not consumed yet (nullptr: none), snext = the block's next scores
   // (accumulated, or still accumulating - their MFMAs may be in flight -, not yet exponentiated).
   auto lazy_rebase = [&](int j, float part, u32x4_t (*w)[4], f32x16_t* snext) __attribute__((always_inline)) {
-#ifdef AM_LAZY_DEBUG
-    if (lane == 0) atomicAdd(flags - 3 + j, 1u);
-#endif
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
     const float rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // the row's sum over the tile, same in both half-lanes
     const bool bad = !(rs < 0x1p60f);
@@ -750,27 +747,44 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 
 }  // namespace
 
-// Per-device mark buffer of the LAZY kernel (one word per workgroup, all zero between launches: the exact fallback
-// clears what the lazy pass set).  Grow-only; launches on one device are issued from one thread (C-ABI contract).
-static unsigned* g_flag_buf[64] = {};      // [0] = workgroups the exact fallback has recomputed so far, [4..] = marks
-static int64_t g_flag_cap[64] = {};
+// Per-device mark buffers of the LAZY kernel: G_REGIONS regions of [4 header words | one mark word per workgroup], all marks
+// zero between launches (the exact fallback clears what the lazy pass set).  Consecutive launches (a lazy kernel + its
+// fallback) rotate through the regions, so launches that overlap on different streams of one device do not share marks.
+// Header word 0 of a region counts the workgroups its fallbacks have recomputed.  Grow-only; launches on one device are
+// issued from one thread (C-ABI contract).
+constexpr int G_REGIONS = 8;
+static unsigned* g_flag_buf[64] = {};
+static int64_t g_flag_cap[64] = {};        // mark words per region
+static uint64_t g_flag_launch[64] = {};
+static uint64_t g_flag_carry[64] = {};     // counts carried over a re-allocation
+static int lazy_flag_total(int dev, uint64_t* total) {
+  *total = g_flag_carry[dev];
+  if (g_flag_buf[dev]) {
+    AM_HIP(hipDeviceSynchronize());
+    for (int r = 0; r < G_REGIONS; ++r) {
+      unsigned c = 0;
+      AM_HIP(hipMemcpy(&c, g_flag_buf[dev] + (size_t)r * (g_flag_cap[dev] + 4), sizeof(c), hipMemcpyDeviceToHost));
+      *total += c;
+    }
+  }
+  return AM_OK;
+}
 static int lazy_flags(int64_t n, unsigned** out) {
   int dev = 0;
   AM_HIP(hipGetDevice(&dev));
   AM_CHECK(dev >= 0 && dev < 64, "am_attention64: device index %d", dev);
   if (g_flag_cap[dev] < n) {
-    unsigned count = 0;
-    if (g_flag_buf[dev]) {
-      AM_HIP(hipDeviceSynchronize());
-      AM_HIP(hipMemcpy(&count, g_flag_buf[dev], sizeof(count), hipMemcpyDeviceToHost));
-      AM_HIP(hipFree(g_flag_buf[dev]));
-    }
-    g_flag_cap[dev] = n > (1 << 18) ? n : (1 << 18);
-    AM_HIP(hipMalloc(&g_flag_buf[dev], (g_flag_cap[dev] + 4) * sizeof(unsigned)));
-    AM_HIP(hipMemset(g_flag_buf[dev], 0, (g_flag_cap[dev] + 4) * sizeof(unsigned)));
-    AM_HIP(hipMemcpy(g_flag_buf[dev], &count, sizeof(count), hipMemcpyHostToDevice));
+    uint64_t total = 0;
+    AM_TRY(lazy_flag_total(dev, &total));
+    if (g_flag_buf[dev]) AM_HIP(hipFree(g_flag_buf[dev]));
+    g_flag_carry[dev] = total;
+    g_flag_cap[dev] = n > (1 << 17) ? n : (1 << 17);
+    const size_t words = (size_t)G_REGIONS * (g_flag_cap[dev] + 4);
+    AM_HIP(hipMalloc(&g_flag_buf[dev], words * sizeof(unsigned)));
+    AM_HIP(hipMemset(g_flag_buf[dev], 0, words * sizeof(unsigned)));
   }
-  *out = g_flag_buf[dev] + 4;
+  const int region = (int)(g_flag_launch[dev]++ % G_REGIONS);
+  *out = g_flag_buf[dev] + (size_t)region * (g_flag_cap[dev] + 4) + 4;
   return AM_OK;
 }
 // Diagnostic (tests): number of workgroups of the current device the exact fallback kernel has recomputed since the
@@ -780,19 +794,7 @@ extern "C" int am_attention_fallback_count(uint64_t* count) {
   int dev = 0;
   AM_HIP(hipGetDevice(&dev));
   AM_CHECK(dev >= 0 && dev < 64, "am_attention_fallback_count: device index %d", dev);
-  unsigned c = 0;
-  if (g_flag_buf[dev]) {
-    AM_HIP(hipDeviceSynchronize());
-    AM_HIP(hipMemcpy(&c, g_flag_buf[dev], sizeof(c), hipMemcpyDeviceToHost));
-#ifdef AM_LAZY_DEBUG
-    unsigned r[2] = {0, 0};
-    AM_HIP(hipMemcpy(r, g_flag_buf[dev] + 1, sizeof(r), hipMemcpyDeviceToHost));
-    *count = (uint64_t)c | ((uint64_t)r[0] << 20) | ((uint64_t)r[1] << 40);
-    return AM_OK;
-#endif
-  }
-  *count = c;
-  return AM_OK;
+  return lazy_flag_total(dev, count);
 }
 
 // Main (non-split) grid of the 4x64 kernel: query blocks [0, nblk_main) of every (sequence, head).

@@ -210,10 +210,7 @@ typedef struct {
   float* state;
 } am_attn_args;
 int am_attention_bf16(const am_attn_args* args, void* stream);
-/* Note: the long-key-stream kernel and its exact fallback communicate through one per-device mark buffer owned by the
- * library: attention launches on ONE device must be serialised on one stream (the reference's single-threaded driver
- * does that; the multi-GPU overlap path runs RCCL, not a second attention, beside it).
- * Diagnostic: the long-key-stream kernel keeps no running row max in its loop (it re-bases lazily from the row sums);
+/* Diagnostic: the long-key-stream kernel keeps no running row max in its loop (it re-bases lazily from the row sums);
  * a workgroup that meets a single-tile jump of more than 2^60 is recomputed by an exact kernel launched behind it.
  * Returns how many workgroups that fallback has recomputed on the current device so far (synchronises the device). */
 int am_attention_fallback_count(uint64_t* count);

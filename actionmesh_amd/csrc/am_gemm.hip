@@ -415,8 +415,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
 
 }  // namespace
 
-int am_gemm4w_launch(const am_gemm_args* a, int tiles_m, int tiles_n, void* stream);     // am_gemm4w.hip
-
 extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_gemm_bf16: null args");
   AM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "am_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -437,11 +435,9 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
     attr_set = true;
   }
-  // act bit 8 (0x100) forces the 128x128 register-staged kernel, bit 9 (0x200) selects the hand-placed 4-wave main loop of
-  // am_gemm4w.hip instead of the 8-wave 256x256 kernel (A/B measurements / tests; bit-identical results)
+  // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings)
   am_gemm_args args = *a;
   const bool force_small = (args.act & 0x100) != 0;
-  const bool use_4wave = (args.act & 0x200) != 0;
   args.act &= 0xff;
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
   // the 256x256 tiles need a grid that fills the 256 CUs; mid-sized problems (the context encoder's 16 x 257 rows)
@@ -455,10 +451,8 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
     const int rem = args.M % B2;
     const int m_main = (rem != 0 && rem <= 128 && args.M > 8 * B2) ? args.M - rem : args.M;
     const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
-    if (use_4wave) AM_TRY(am_gemm4w_launch(&args, tiles_m, tiles_n, stream));
-    else
-      hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
-                         (hipStream_t)stream, args, tiles_m, tiles_n, 0);
+    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
+                       (hipStream_t)stream, args, tiles_m, tiles_n, 0);
     if (m_main < args.M) {
       const int tn = ceil_div(args.N, BN);
       hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);

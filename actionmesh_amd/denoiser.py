@@ -45,12 +45,31 @@ def masked_time(diffusion_time: Sequence[float], mask: Optional[torch.Tensor], B
     return [t * (1.0 - mm) for t, mm in zip(t_rep, m)]
 
 
-class WindowCache:
-    """Opaque `freqs_rot` object handed back to the sampler (scheduler.py:224-232): proves that
-    the step-invariant state (RoPE table + cross-attention K/V cache) of this window is bound."""
+def _tensor_identity(t: torch.Tensor) -> Tuple:
+    """Cheap identity of a tensor's current contents: storage address, geometry and torch's in-place version counter."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, str(t.device), t._version)
 
-    def __init__(self, generation: int):
+
+class WindowCache:
+    """Opaque `freqs_rot` object handed back to the sampler (scheduler.py:224-232).
+
+    In the reference `freqs_rot` caches the RoPE table only; here a bound window also holds the cross-attention K/V
+    cache of ONE context tensor.  The reference sampler with `split_cfg_batch: true` (actionmesh_lowram.yaml) calls
+    forward once per CFG branch with `context[b:b+1]` and hands every branch the `freqs_rot` branch 0 returned, so the
+    cache is tied to the context (storage address, geometry, in-place version) and the framesteps it was built from:
+    a call with any other context re-binds instead of silently reusing the first branch's K/V."""
+
+    def __init__(self, generation: int, context: Optional[torch.Tensor] = None,
+                 framestep: Optional[torch.Tensor] = None, n_tokens: int = 0):
         self.generation = generation
+        self._context_ref = context        # kept alive: a freed tensor's address could be handed to a different context
+        self.context_id = None if context is None else _tensor_identity(context)
+        self.framestep = None if framestep is None else framestep.detach().float().cpu().reshape(-1).tolist()
+        self.n_tokens = n_tokens
+
+    def matches(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int) -> bool:
+        return (self.context_id == _tensor_identity(context) and self.n_tokens == n_tokens
+                and self.framestep == framestep.detach().float().cpu().reshape(-1).tolist())
 
 
 class HipEngine:
@@ -297,8 +316,21 @@ class HipDenoiser(nn.Module):
         sin = plan.slice_local(sin.view(B, T, -1)).reshape(-1, HEAD_DIM // 2)
         e.set_context(plan.slice_local(context), cos, sin)
         self._generation += 1
-        self._window = WindowCache(self._generation)
+        self._window = WindowCache(self._generation, context, framestep, n_tokens)
         return self._window
+
+    def _apply(self, fn, recurse: bool = True):
+        """`.to()` / `.cpu()` / `.cuda()`: the engine (weights, workspace, K/V caches in HBM) belongs to one device.
+        Leaving it - the reference's `--low_ram` unload moves the denoiser to the CPU between stages
+        (pipeline.py:171-184) - frees every byte the engine holds; the host copy of the weights stays, and the next
+        forward on a GPU builds a fresh engine there."""
+        out = super()._apply(fn, recurse)
+        e = self._engine
+        if e is not None and e.device != self.device:
+            e.close()
+            self._engine = None
+            self._window = None
+        return out
 
     def forward_host_time(self, hidden_states: torch.Tensor, t_bt: List[float]) -> torch.Tensor:
         """Forward with the masked per-(b,t) diffusion times already on the host."""
@@ -321,7 +353,8 @@ class HipDenoiser(nn.Module):
                 freqs_rot: Optional[WindowCache] = None):
         B, T, N, _ = hidden_states.shape
         if not (isinstance(freqs_rot, WindowCache) and self._window is not None
-                and freqs_rot.generation == self._window.generation):
+                and freqs_rot.generation == self._window.generation
+                and self._window.matches(context, framestep, N)):
             freqs_rot = self.bind_window(context, framestep, N)
         t_bt = masked_time(diffusion_time.detach().float().cpu().tolist(), mask, B, T)
         return self.forward_host_time(hidden_states, t_bt), freqs_rot

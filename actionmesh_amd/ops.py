@@ -16,8 +16,17 @@ from . import _lib as L
 HEAD_DIM = 128
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """torch's current stream of `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _launch(t: torch.Tensor, fn, what: str, *args) -> None:
+    """Call a C-ABI kernel entry point on the device that owns `t`: the device is made current for the call (the
+    library launches on the current device) and the stream is torch's current stream OF THAT DEVICE, so a tensor on a
+    non-current device is neither launched on device 0's stream nor unordered with the work that produced it."""
+    with torch.cuda.device(t.device):
+        L.check(fn(*args, _stream(t.device)), what)
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -48,7 +57,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, gelu: bool = False,
          a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
-         M: Optional[int] = None, force_small: bool = False, use_4wave: bool = False) -> torch.Tensor:
+         M: Optional[int] = None, force_small: bool = False) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
@@ -75,11 +84,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.residual = _p(_need(residual, torch.bfloat16, "residual")) if residual is not None else None
     g.C = out.data_ptr(); g.ldc = out.stride(0)
     g.M, g.N, g.K = M, N, K
-    # 0x100: force the 128x128 kernel; 0x200: the hand-placed 4-wave main loop instead of the 8-wave 256x256 kernel (A/B)
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if use_4wave else 0)
+    # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
-    L.check(L.lib().am_gemm_bf16(C.byref(g), _stream()), "am_gemm_bf16")
+    _launch(a, L.lib().am_gemm_bf16, "am_gemm_bf16", C.byref(g))
     return out
 
 
@@ -90,8 +99,8 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
     rows = x.numel() // Cdim
     if out is None:
         out = torch.empty_like(x)
-    L.check(L.lib().am_layernorm_bf16(x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                      rows, Cdim, eps, _stream()), "am_layernorm_bf16")
+    _launch(x, L.lib().am_layernorm_bf16, "am_layernorm_bf16", x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                      rows, Cdim, eps)
     return out
 
 
@@ -127,7 +136,7 @@ def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, r
     a.out_q = _p(out_q); a.sq_pad = out_q.shape[2] if out_q is not None else 0
     a.out_k = _p(out_k); a.out_vt = _p(out_vt)
     a.sk_pad = out_k.shape[2] if out_k is not None else (out_vt.shape[3] if out_vt is not None else 0)
-    L.check(L.lib().am_head_post(C.byref(a), _stream()), "am_head_post")
+    _launch(x, L.lib().am_head_post, "am_head_post", C.byref(a))
     return out_q, out_k, out_vt
 
 
@@ -162,7 +171,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
         _need(state, torch.float32, "state")
         assert state.numel() >= nseq * H * sq_pad * STATE_LD
         a.state = state.data_ptr()
-    L.check(L.lib().am_attention_bf16(C.byref(a), _stream()), "am_attention_bf16")
+    _launch(q, L.lib().am_attention_bf16, "am_attention_bf16", C.byref(a))
     return out
 
 
@@ -176,15 +185,14 @@ def attention_fallback_count() -> int:
 def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
     _need(x, torch.float32, "x")
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    L.check(L.lib().am_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "am_f32_to_bf16")
+    _launch(x, L.lib().am_f32_to_bf16, "am_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel())
     return y
 
 
 def timestep_sinusoid(t: torch.Tensor, width: int) -> torch.Tensor:
     _need(t, torch.float32, "t")
     y = torch.empty((t.numel(), width), dtype=torch.bfloat16, device=t.device)
-    L.check(L.lib().am_timestep_sinusoid(t.data_ptr(), y.data_ptr(), t.numel(), width, _stream()),
-            "am_timestep_sinusoid")
+    _launch(t, L.lib().am_timestep_sinusoid, "am_timestep_sinusoid", t.data_ptr(), y.data_ptr(), t.numel(), width)
     return y
 
 
@@ -194,8 +202,8 @@ def point_embed(query: torch.Tensor, in_channels: int, extra_channels: int, num_
     _need(query, torch.float32, "query")
     rows = query.shape[0]
     out = torch.empty((rows, ld_out), dtype=torch.bfloat16, device=query.device)
-    L.check(L.lib().am_point_embed(query.data_ptr(), query.stride(0), rows, in_channels, extra_channels, num_freqs,
-                                   int(include_pi), out.data_ptr(), ld_out, _stream()), "am_point_embed")
+    _launch(query, L.lib().am_point_embed, "am_point_embed", query.data_ptr(), query.stride(0), rows, in_channels, extra_channels, num_freqs,
+                                   int(include_pi), out.data_ptr(), ld_out)
     return out
 
 
@@ -205,15 +213,14 @@ def patchify(pixels: torch.Tensor, patch: int, ld_out: int) -> torch.Tensor:
     _need(pixels, torch.float32, "pixels")
     T, Cin, H, W = pixels.shape
     out = torch.empty((T * (H // patch) * (W // patch), ld_out), dtype=torch.bfloat16, device=pixels.device)
-    L.check(L.lib().am_patchify(pixels.data_ptr(), T, Cin, H, W, patch, out.data_ptr(), ld_out, _stream()), "am_patchify")
+    _launch(pixels, L.lib().am_patchify, "am_patchify", pixels.data_ptr(), T, Cin, H, W, patch, out.data_ptr(), ld_out)
     return out
 
 
 def displacement(logits: torch.Tensor, out_dim: int, out: torch.Tensor) -> torch.Tensor:
     """out (rows, out_dim) fp32 = 2 sigmoid(-logits[:, :out_dim]) - 1."""
     _need(logits, torch.bfloat16, "logits"); _need(out, torch.float32, "out")
-    L.check(L.lib().am_displacement(logits.data_ptr(), logits.stride(0), logits.shape[0], out_dim, out.data_ptr(), _stream()),
-            "am_displacement")
+    _launch(logits, L.lib().am_displacement, "am_displacement", logits.data_ptr(), logits.stride(0), logits.shape[0], out_dim, out.data_ptr())
     return out
 
 
@@ -226,5 +233,5 @@ def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], d
     un = None
     if unobserved is not None:
         un = (C.c_uint8 * T)(*[1 if u else 0 for u in unobserved])
-    L.check(L.lib().am_flow_step(v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
-                                 un, T, N, D, _stream()), "am_flow_step")
+    _launch(v, L.lib().am_flow_step, "am_flow_step", v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
+                                 un, T, N, D)

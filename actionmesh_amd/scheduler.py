@@ -72,7 +72,12 @@ class HipSchedulerFlow:
     num_train_timesteps: int = 1000
     shift: float = 3.0
     is_additive: bool = False
-    split_cfg_batch: bool = False   # accepted for config parity; the HIP path always batches CFG
+    split_cfg_batch: bool = False   # scheduler.py:150-170: one forward per CFG branch (half the activation workspace)
+    # Not a reference field.  The reference's GPU path multiplies `distances[i]` (a 0-dim fp32 DEVICE tensor) with the bf16
+    # velocity, and torch's type promotion rounds the distance to bf16 first (scheduler.py:238-241 under cuda autocast; its
+    # fp32 CPU path does not).  False (default) keeps dt in fp32 = the reference's CPU arithmetic; True reproduces the
+    # cuda-autocast rounding bit for bit.
+    cuda_autocast_dt: bool = False
 
     def get_schedule(self):
         """scheduler.py:43-56."""
@@ -131,17 +136,34 @@ class HipSchedulerFlow:
                 for g in branches]
 
         timesteps, distances = self.get_schedule()
-        diffusion_model.bind_window(ctx_b, fs_b, N)
+        split = self.split_cfg_batch and nb > 1
+        if not split:
+            diffusion_model.bind_window(ctx_b, fs_b, N)
         it = range(self.num_inference_steps)
         if not disable_prog:
             from tqdm import tqdm
             it = tqdm(it, desc="Temporal 3D Denoising (Stage I)", leave=True)
         for i in it:
             t = float(timesteps[i])
-            t_bt = [t * k for row in keep for k in row]                  # temporal_denoiser.py:209-212
-            x_in = latents.expand(nb, T, N, D).contiguous()
-            v = diffusion_model.forward_host_time(x_in, t_bt)
-            ops.flow_step(v, latents[0], scales, float(distances[i]), self.is_additive, unobserved)
+            dt = float(distances[i])
+            if self.cuda_autocast_dt:
+                dt = float(torch.tensor(dt, dtype=torch.float32).to(torch.bfloat16))
+            # every launch of the step goes to the denoiser's device and that device's current stream, whichever device is
+            # current in the calling thread (the forward and the CFG+Euler kernel must share a stream to be ordered)
+            with torch.cuda.device(dev):
+                if split:
+                    # scheduler.py:159-168: branch by branch, each with its own slice of the context (the window is re-bound
+                    # per branch: the K/V cache holds one context at a time, as the reference recomputes K/V every call)
+                    vs = []
+                    for b in range(nb):
+                        diffusion_model.bind_window(ctx_b[b:b + 1], fs_b[b:b + 1], N)
+                        vs.append(diffusion_model.forward_host_time(latents, [t * k for k in keep[b]]))
+                    v = torch.cat(vs, dim=0)
+                else:
+                    t_bt = [t * k for row in keep for k in row]              # temporal_denoiser.py:209-212
+                    x_in = latents.expand(nb, T, N, D).contiguous()
+                    v = diffusion_model.forward_host_time(x_in, t_bt)
+                ops.flow_step(v, latents[0], scales, dt, self.is_additive, unobserved)
             yield latents, timesteps[i]
 
     @torch.no_grad()

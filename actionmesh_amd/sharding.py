@@ -44,22 +44,32 @@ class FrameShardPlan:
             raise ValueError(f"bad rank {self.rank} / world {self.world}")
         if self.cfg_groups < 1 or self.world % self.cfg_groups or self.batch % self.cfg_groups:
             raise ValueError(f"cfg_groups={self.cfg_groups} must divide world={self.world} and batch={self.batch}")
-        if self.n_frames % self.frame_world != 0:
-            raise ValueError(
-                f"{self.n_frames} frames do not divide over {self.frame_world} frame shards "
-                "(the reference window is 16 frames: use 1, 2, 4, 8 or 16 ranks per CFG branch)")
+        if self.n_frames < 1:
+            raise ValueError(f"n_frames={self.n_frames}")
 
     @property
-    def frame_world(self) -> int:          # ranks sharing one CFG group = frame shards
+    def group_size(self) -> int:           # ranks sharing one CFG group
         return self.world // self.cfg_groups
 
     @property
+    def frame_world(self) -> int:
+        """Frame shards per CFG group.  The reference's chunk_right / chunk_from produce windows shorter than 16
+        frames when the video is shorter than the window (5, 7 ... frames); a frame count the group does not divide
+        is not sharded at all: every rank of the group then computes all frames of its CFG branch (replicas, no K/V
+        exchange) instead of the run failing on inputs the single-GPU path handles."""
+        return self.group_size if self.n_frames % self.group_size == 0 else 1
+
+    @property
+    def replicated(self) -> bool:
+        return self.frame_world != self.group_size
+
+    @property
     def frame_rank(self) -> int:
-        return self.rank % self.frame_world
+        return (self.rank % self.group_size) if not self.replicated else 0
 
     @property
     def cfg_rank(self) -> int:
-        return self.rank // self.frame_world
+        return self.rank // self.group_size
 
     @property
     def frames_local(self) -> int:
@@ -78,7 +88,7 @@ class FrameShardPlan:
         return slice(self.cfg_rank * self.batch_local, (self.cfg_rank + 1) * self.batch_local)
 
     def frame_group_ranks(self, cfg_rank: int) -> List[int]:
-        return [cfg_rank * self.frame_world + r for r in range(self.frame_world)]
+        return [cfg_rank * self.group_size + r for r in range(self.group_size)]
 
     def slice_frames(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
         """Local frames of a (B, T, ...) tensor (contiguous copy); the batch is left alone."""
@@ -149,11 +159,11 @@ def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.P
 def gather_frames(v_local: torch.Tensor, plan: FrameShardPlan,
                   group: Optional[dist.ProcessGroup]) -> torch.Tensor:
     """(B_local, T_local, ...) on every rank -> (B, T, ...) on every rank (`group` = all ranks).
-    Rank g*frame_world + r holds batch block g, frame shard r."""
+    Rank g*group_size + r holds batch block g, frame shard r."""
     if plan.world == 1:
         return v_local
     parts = [torch.empty_like(v_local) for _ in range(plan.world)]
     dist.all_gather(parts, v_local.contiguous(), group=group)
-    fw = plan.frame_world
-    rows = [torch.cat(parts[g * fw:(g + 1) * fw], dim=1) for g in range(plan.cfg_groups)]
+    gs, fw = plan.group_size, plan.frame_world      # replicated groups: the first rank's copy stands for the group
+    rows = [torch.cat(parts[g * gs:g * gs + fw], dim=1) for g in range(plan.cfg_groups)]
     return torch.cat(rows, dim=0)

@@ -1,0 +1,176 @@
+"""Model-level parity at the BASELINE architectures (GPU): 21 layers (skip depth 10), head_dim 128, Dc 1024, S 257,
+width 1024 / 8 heads (the headline "16f x 4096tok x 1024-dim" architecture) and width 2048 / 16 heads (the shipped
+one), many sampler steps, through the C-ABI, against fixtures the reference's own unmodified modules produced
+(oracle/make_golden_baseline.py -> tests/golden/arch_*.npz).  Weights and inputs are regenerated from seeded CPU
+generators and pinned by the checksums stored in the fixtures.
+
+Stated tolerance (per-step latents on the stored token subset, rel-L2 vs the reference's fp32 run):
+    tol(step) = min(2e-2 + 2.5e-3 * step, 8e-2)        plain weights (unit qk-norm gains)
+i.e. the 2e-2 single-forward / few-step bound of tests/test_denoiser_gpu.py plus a linear allowance for the error a
+bf16 velocity accumulates through an Euler loop (each step adds d_i * 7.5 * (v1 - v0) with both velocities carrying
+independent bf16-level error; DESIGN.md section 2 holds the measured curve).  For scale the fixtures carry the reference's
+OWN reduced-precision curve (the same modules under autocast(bf16) vs their fp32 run, `ref_autocast_curve`): the HIP
+path must not be further from fp32 than 1.5x that curve + 1e-2 either.
+Peaky / spiky weights (qk-norm gains x4 / x7: scores ~ N(0, 16^2), softmax close to one-hot) are chaotic in ANY reduced
+precision (the reference under autocast(bf16) is 0.5 rel-L2 from its own fp32 forward on these cases), so those cases
+assert what is well defined: finite outputs, the data-dependent branches of the attention kernel really fire inside the
+model (exact-fallback counter), the lazy product kernel and the exact kernel agree inside the full model, and the
+HIP forward is closer to the fp32 reference than the reference's own autocast run is.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from actionmesh_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def _case(name, golden_dir, dev, **model_kw):
+    from actionmesh_amd import HipDenoiser
+    from oracle.denoiser_oracle import state_dict_checksum
+    from oracle.make_golden_baseline import baseline_case_inputs, tensor_checksum
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    kw, cfg, sd, inp, steps = baseline_case_inputs(name)
+    assert state_dict_checksum(sd) == pytest.approx(float(g["weights_checksum"]), rel=1e-12)
+    got = [tensor_checksum(inp[k]) for k in ("init_latent", "context", "mask", "framestep")]
+    assert np.allclose(got, g["inputs_checksum"], rtol=1e-12)
+    model = HipDenoiser(num_tokens_nominal=inp["init_latent"].shape[2], temporal_context_size=inp["init_latent"].shape[1],
+                        **kw, **model_kw)
+    model.load_state_dict(sd)
+    model.to(dev).eval()
+    return g, cfg, sd, model, inp, steps
+
+
+def _forward(model, inp, t, dev):
+    from actionmesh_amd import ClassifierFreeGuidance
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(inp["init_latent"], inp["context"], inp["mask"], inp["framestep"])
+    tt = torch.tensor([t]).expand(2)
+    v, _ = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+    torch.cuda.synchronize()
+    return v.float().cpu()
+
+
+def _record(name, payload):
+    """Curves go to gpurun_out/ (scratch) so the numbers quoted in DESIGN.md can be regenerated."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+            json.dump(payload, f, indent=1)
+    except OSError:
+        pass
+
+
+def tol_plain(step):
+    return min(2e-2 + 2.5e-3 * step, 8e-2)
+
+
+@pytest.mark.parametrize("name", ["arch_headline", "arch_nominal"])
+def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name):
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev)
+    stride = int(g["token_stride"])
+    v = _forward(model, inp, float(g["fwd_t"]), dev)
+    r_fwd = rel(v, torch.from_numpy(g["fwd_velocity_fp32"]))
+    print(f"{name}: forward rel-L2 vs reference fp32 {r_fwd:.3e} (reference autocast vs fp32: {float(g['fwd_ref_autocast_vs_fp32']):.3e})")
+    assert torch.isfinite(v).all() and r_fwd < 2e-2
+
+    sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    ref = torch.from_numpy(g["loop_latents_sub_fp32"])
+    ref_curve = g["ref_autocast_curve"]
+    init = inp["init_latent"].clone().to(dev)
+    curve, last = [], None
+    for i, (lat, _t) in enumerate(sched._flow_sample(model, cfgd, init, inp["context"].to(dev), device=dev,
+                                                     mask=inp["mask"].to(dev), framestep=inp["framestep"].to(dev))):
+        sub = lat[:, :, ::stride].cpu()
+        curve.append(rel(sub, ref[i]))
+        assert torch.equal(sub[0, 0], inp["init_latent"][0, 0, ::stride]), "conditioning frame must stay untouched"
+        last = lat
+    assert len(curve) == steps
+    final = rel(last.cpu(), torch.from_numpy(g["loop_final_fp32"]))
+    print(f"{name}: per-step latents rel-L2 vs reference fp32: " + " ".join(f"{c:.2e}" for c in curve))
+    print(f"{name}: reference autocast(bf16) vs its fp32:       " + " ".join(f"{c:.2e}" for c in ref_curve))
+    print(f"{name}: final full latents rel-L2 {final:.3e}")
+    _record(name, dict(forward=r_fwd, curve=curve, ref_autocast_curve=[float(c) for c in ref_curve], final=final))
+    for i, c in enumerate(curve):
+        assert c < tol_plain(i), (i, c, tol_plain(i))
+        if i < len(ref_curve):
+            assert c < 1.5 * float(ref_curve[i]) + 1e-2, (i, c, float(ref_curve[i]))
+    assert final < tol_plain(steps - 1)
+
+
+@pytest.mark.parametrize("name", ["arch_headline_peaky", "arch_headline_spiky"])
+def test_peaky_attention_inside_the_full_model(dev, golden_dir, name):
+    """Trained qk-norm gains make attention peaky; the lazy re-base (peaky) and the exact fallback (spiky) of the product
+    attention kernel must fire inside the 21-layer model and leave the result equal to the exact kernel's."""
+    from actionmesh_amd import _lib
+    import ctypes as C
+    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev)
+    lib = _lib.lib()
+
+    def fallbacks():
+        n = C.c_uint64()
+        _lib.check(lib.am_attention_fallback_count(C.byref(n)), "am_attention_fallback_count")
+        return n.value
+
+    f0 = fallbacks()
+    v_lazy = _forward(model, inp, float(g["fwd_t"]), dev)
+    fired = fallbacks() - f0
+    assert torch.isfinite(v_lazy).all()
+    model.cpu()
+    # the exact kernel (running row max, immediate re-base) inside the same model
+    g2, _, _, exact, _, _ = _case(name, golden_dir, dev, attn_defer_log2=0)
+    v_exact = _forward(exact, inp, float(g["fwd_t"]), dev)
+    ref = torch.from_numpy(g["fwd_velocity_fp32"])
+    r_lazy, r_exact, r_pair = rel(v_lazy, ref), rel(v_exact, ref), rel(v_lazy, v_exact)
+    ref_ac = float(g["fwd_ref_autocast_vs_fp32"])
+    print(f"{name}: forward rel-L2 vs reference fp32: lazy {r_lazy:.3e}, exact {r_exact:.3e}; lazy vs exact {r_pair:.3e}; "
+          f"reference autocast(bf16) vs its fp32 {ref_ac:.3e}; exact-fallback workgroups {fired}")
+    _record(name, dict(lazy=r_lazy, exact=r_exact, lazy_vs_exact=r_pair, ref_autocast=ref_ac, fallback_workgroups=fired))
+    if name.endswith("spiky"):
+        assert fired > 0, "the spiky case is built to need the exact fallback"
+    # the two softmax algorithms see the same bf16 operands: they may differ by fp32 rounding of the probabilities only,
+    # amplified by the near-one-hot softmax of the following layers
+    assert r_pair < 0.35 * max(r_lazy, r_exact) + 2e-2
+    assert r_lazy < ref_ac and r_exact < ref_ac
+
+
+def test_peaky_loop_stays_finite_and_anchored(dev, golden_dir):
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    name = "arch_headline_peaky"
+    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev)
+    stride = int(g["token_stride"])
+    sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    ref = torch.from_numpy(g["loop_latents_sub_fp32"])
+    init = inp["init_latent"].clone().to(dev)
+    curve = []
+    for i, (lat, _t) in enumerate(sched._flow_sample(model, cfgd, init, inp["context"].to(dev), device=dev,
+                                                     mask=inp["mask"].to(dev), framestep=inp["framestep"].to(dev))):
+        sub = lat[:, :, ::stride].cpu()
+        assert torch.isfinite(sub).all()
+        assert torch.equal(sub[0, 0], inp["init_latent"][0, 0, ::stride])
+        curve.append(rel(sub, ref[i]))
+    ref_curve = [float(c) for c in g["ref_autocast_curve"]]
+    print(f"{name}: per-step latents rel-L2 vs reference fp32: " + " ".join(f"{c:.2e}" for c in curve))
+    print(f"{name}: reference autocast(bf16) vs its fp32:       " + " ".join(f"{c:.2e}" for c in ref_curve))
+    _record(name + "_loop", dict(curve=curve, ref_autocast_curve=ref_curve))
+    for i, c in enumerate(curve):
+        assert c < ref_curve[i], (i, c, ref_curve[i])

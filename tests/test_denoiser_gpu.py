@@ -362,3 +362,88 @@ def test_autoregressive_windows_match_oracle(dev):
     per_frame = [rel(lat[i].cpu(), lat_ref[i]) for i in range(T) if i != 2]
     print("AR windows: per-frame rel-L2 vs fp32 oracle", [f"{r:.2e}" for r in per_frame])
     assert max(per_frame) < 3e-2
+
+
+def test_split_cfg_batch_style_loop_rebinds_the_context(dev, golden_dir):
+    """the reference SchedulerFlow with split_cfg_batch=True (actionmesh_lowram.yaml) calls forward once per
+    CFG branch with context[b:b+1] and hands every call the freqs_rot branch 0 returned.  Branch 0 is the zeroed context;
+    the window cache must follow the context, not the cache object, or the image conditioning is silently lost."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    g, cfg, sd, model, t = _setup("tiny_inflated", golden_dir, dev)
+    steps = int(g["steps"])
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+    ts, ds = sched.get_schedule()
+    lat = t["init_latent"].clone().to(dev)
+    ctx, mask, fs = t["context"].to(dev), t["mask"].to(dev), t["framestep"].to(dev)
+    unobs = cfgd.get_unobserved_mask(mask)
+    cache = None
+    for i in range(steps):
+        x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(lat, ctx, mask, fs)
+        dt = torch.tensor([float(ts[i])], device=dev).expand(2)
+        outs = []
+        for b in range(2):                                  # scheduler.py:159-168
+            o, cache = model.forward(hidden_states=x_in[b:b + 1], context=c_in[b:b + 1], framestep=f_in[b:b + 1],
+                                     mask=m_in[b:b + 1], diffusion_time=dt[b:b + 1], freqs_rot=cache)
+            outs.append(o)
+        v = cfgd.aggregate_cfg(torch.cat(outs, dim=0))
+        flow = lat + (float(ds[i]) * v.float()).to(torch.bfloat16)
+        lat[unobs] = flow[unobs]
+    ref = torch.from_numpy(g["loop_final_split_cfg_fp32"])
+    r = rel(lat.cpu(), ref)
+    print(f"split_cfg_batch-style loop: final latents rel-L2 vs the reference's split run {r:.3e}")
+    assert r < 2e-2
+    # the sampler's own split mode: one forward per branch, same result as its batched mode to bf16 rounding
+    a = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True, split_cfg_batch=True).denoise(
+        model, cfgd, init_latent=t["init_latent"].clone().to(dev), context=ctx, device=dev, mask=mask, framestep=fs)
+    b = sched.denoise(model, cfgd, init_latent=t["init_latent"].clone().to(dev), context=ctx, device=dev, mask=mask,
+                      framestep=fs)
+    assert rel(a.cpu(), ref) < 2e-2 and rel(a.cpu(), b.cpu()) < 5e-3
+
+
+def test_cuda_autocast_dt_switch(dev, golden_dir):
+    """`cuda_autocast_dt=True` reproduces the reference GPU path's bf16 rounding of distances[i] (scheduler.py:238-241
+    under cuda autocast); the default keeps it fp32 like the reference's CPU path.  One step: the two differ by exactly
+    the rounding of dt."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    g, cfg, sd, model, t = _setup("tiny_inflated", golden_dir, dev)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    outs = {}
+    for flag in (False, True):
+        s = HipSchedulerFlow(num_inference_steps=1, shift=3.0, is_additive=True, cuda_autocast_dt=flag)
+        outs[flag] = s.denoise(model, cfgd, init_latent=t["init_latent"].clone().to(dev), context=t["context"].to(dev),
+                               device=dev, mask=t["mask"].to(dev), framestep=t["framestep"].to(dev)).cpu()
+    d = float(HipSchedulerFlow(num_inference_steps=1, shift=3.0).get_schedule()[1][0])
+    d_bf = float(torch.tensor(d).to(torch.bfloat16))
+    assert d != d_bf
+    x0 = t["init_latent"]
+    step32, stepbf = outs[False] - x0, outs[True] - x0
+    ratio = float((stepbf[0, 1:] * step32[0, 1:]).sum() / (step32[0, 1:] ** 2).sum())
+    assert ratio == pytest.approx(d_bf / d, rel=2e-3)
+    assert torch.equal(outs[True][0, 0], x0[0, 0])
+
+
+def test_moving_to_cpu_releases_the_engine(dev, golden_dir):
+    """`--low_ram` semantics (pipeline.py:171-184): the reference unloads a stage with `.to("cpu")`; for HipDenoiser that
+    must free the engine's HBM (weights, workspace, K/V caches), and a later `.to(device)` + forward must work again."""
+    g, cfg, sd, model, t = _setup("tiny_inflated", golden_dir, dev)
+    from actionmesh_amd import ClassifierFreeGuidance
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    tt = torch.tensor([float(g["fwd_t"])]).expand(2)
+    args = lambda: (x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+    v0, _ = model.forward(*args())
+    torch.cuda.synchronize()
+    assert model._engine is not None
+    free_with, _ = torch.cuda.mem_get_info(dev)
+    model.to("cpu")
+    assert model._engine is None and model._window is None and model.device.type == "cpu"
+    torch.cuda.synchronize()
+    free_without, _ = torch.cuda.mem_get_info(dev)
+    assert free_without > free_with, (free_with, free_without)
+    with pytest.raises(RuntimeError):
+        model.forward(x_in, c_in, f_in, tt, m_in, None)
+    model.to(dev)
+    v1, _ = model.forward(*args())
+    torch.cuda.synchronize()
+    assert torch.equal(v0, v1)

@@ -120,8 +120,13 @@ def test_frame_shard_plan():
     assert p.frames_local == 4 and p.frame_slice == slice(8, 12)
     x = torch.arange(2 * 16 * 3).view(2, 16, 3)
     assert torch.equal(p.slice_frames(x), x[:, 8:12])
-    with pytest.raises(ValueError):
-        A.FrameShardPlan(16, 3, 0)
+    # a frame count the group does not divide (short windows: chunk_right / chunk_from on 5- or 7-frame videos) is not
+    # sharded: every rank of the group computes all frames (replicas) instead of raising
+    q = A.FrameShardPlan(16, 3, 2)
+    assert q.replicated and (q.frame_world, q.frame_rank, q.frames_local, q.frame_slice) == (1, 0, 16, slice(0, 16))
+    q = A.FrameShardPlan(7, 8, 5, batch=2, cfg_groups=2)
+    assert q.replicated and (q.group_size, q.frame_world, q.cfg_rank, q.frame_rank, q.frames_local) == (4, 1, 1, 0, 7)
+    assert q.local_times(list(range(14))) == list(range(7, 14))
     with pytest.raises(ValueError):
         A.FrameShardPlan(16, 4, 4)
     # CFG-parallel x frame shards: rank = cfg_rank * frame_world + frame_rank
@@ -148,99 +153,30 @@ def test_perm16_is_an_involution_matching_the_mfma_layout():
 
 
 def test_attn64_register_audit(tmp_path):
-    """The 4x64 attention kernel names AccVGPRs a[64:255] literally in inline asm (O accumulators, Q fragments).
-    That is only sound if hipcc itself never touches a[64:255] in that kernel: no scratch spills, and every
-    compiler-generated AccVGPR access (when the kernel needs more than 256 arch VGPRs the allocator parks values in
-    AccVGPRs, lowest free first, whatever the asm clobber lists say) inside a[0:63], which the asm leaves alone
-    (tools/gen_attn64_asm.py; cdna guide 'keep out of registers you name')."""
+    """The 4x64 attention kernel names AccVGPRs a[64:255] literally in inline asm; the ISA audit that makes this sound
+    (actionmesh_amd/csrc/audit_attn64.py: no scratch, no compiler access to a[64:255], no compiler-generated touch of an
+    in-flight QK^T MFMA result) is a Makefile build step; this test runs the same script on a fresh assembly and checks
+    that the script does reject a violation."""
+    import importlib.util
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "actionmesh_amd", "csrc", "am_attention64.hip")
+    csrc = os.path.join(root, "actionmesh_amd", "csrc")
     out = tmp_path / "a64.s"
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mno-amdgpu-ieee", "-fno-honor-nans",
-             "--cuda-device-only", "-S", "-o", str(out), src]
+             "--cuda-device-only", "-S", "-o", str(out), os.path.join(csrc, "am_attention64.hip")]
     subprocess.run([hipcc] + flags, check=True, capture_output=True, timeout=600)
+    spec = importlib.util.spec_from_file_location("audit_attn64", os.path.join(csrc, "audit_attn64.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     text = out.read_text()
-    kernels = re.findall(r"\.agpr_count:\s+(\d+)\n\s+\.name:\s+(\S*attn_fwd64_kernel\S*)\n\s+\.private_segment_fixed_size:\s+(\d+)", text)
-    if not kernels:   # field order differs between compiler versions: fall back to independent searches
-        names = re.findall(r"\.name:\s+(\S*attn_fwd64_kernel\S*)", text)
-        assert names, "no attn_fwd64_kernel in the assembly"
-        kernels = [(a, n, p) for a, n, p in zip(re.findall(r"\.agpr_count:\s+(\d+)", text), names,
-                                                re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text))]
-    for agprs, name, scratch in kernels:
-        assert int(agprs) == 256, f"{name}: {agprs} AccVGPRs allocated, the asm owns a[64:255]"
-        assert int(scratch) == 0, f"{name}: spills to scratch ({scratch} B)"
-    # hipcc may park values in AccVGPRs of its own (a0..a63) - never in the asm-owned range
-    in_asm = False
-    for ln in text.splitlines():
-        code = ln.split(";")[0]
-        if "#ASMSTART" in ln:
-            in_asm = True
-        elif "#ASMEND" in ln:
-            in_asm = False
-        elif not in_asm and re.match(r"\s+(v_|ds_|global_|buffer_|scratch_|flat_)", code):
-            for m in re.finditer(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b", code):
-                lo = int(m.group(1) if m.group(1) is not None else m.group(3))
-                hi_ = int(m.group(2)) if m.group(2) is not None else lo
-                assert hi_ < 64, f"compiler-generated access to an asm-owned AccVGPR: {ln.strip()}"
-    # hipcc does not know the asm statements are MFMAs: nothing it generates (copies, parking in AccVGPRs, softmax steps)
-    # may touch the arch-VGPR destination of a QK^T MFMA within the 11 wait states an 8-pass MFMA needs (14 checked)
-    def vregs(tok):
-        out = set()
-        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
-            out.update(range(int(m.group(1)), int(m.group(2)) + 1) if m.group(1) is not None else [int(m.group(3))])
-        return out
-    in_asm, hot = False, {}
-    for ln in text.splitlines():
-        code = ln.split(";")[0].rstrip()
-        if "#ASMSTART" in ln:
-            in_asm = True
-            continue
-        if "#ASMEND" in ln:
-            in_asm = False
-            continue
-        m = re.match(r"\s+([a-z]\S*)\s*(.*)", code)
-        if not m:
-            continue
-        op, args = m.group(1), m.group(2)
-        step = int(args.strip()) + 1 if op == "s_nop" else 1
-        if not in_asm and op != "s_nop":
-            touched = vregs(args) & set(hot)
-            assert not touched, f"compiler-generated access to an in-flight MFMA result: {ln.strip()}"
-        hot = {k: v - step for k, v in hot.items() if v - step > 0}
-        if in_asm and op.startswith("v_mfma") and args.split(",")[0].strip().startswith("v"):
-            hot.update({r: 14 for r in vregs(args.split(",")[0])})
-
-
-def test_gemm4w_register_audit(tmp_path):
-    """The 4-wave GEMM main loop (am_gemm4w.hip) names all 256 AccVGPRs literally in inline asm: hipcc must not generate
-    a single AccVGPR access of its own in that kernel, and must not spill."""
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "actionmesh_amd", "csrc", "am_gemm4w.hip")
-    out = tmp_path / "g4.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-I", os.path.join(root, "include"),
-                    "-S", "-o", str(out), src], check=True, capture_output=True, timeout=600)
-    text = out.read_text()
-    assert re.search(r"\.agpr_count:\s+256", text) and re.search(r"\.private_segment_fixed_size:\s+0\b", text)
-    in_asm, n_mfma = False, 0
-    for ln in text.splitlines():
-        code = ln.split(";")[0]
-        if "#ASMSTART" in ln:
-            in_asm = True
-        elif "#ASMEND" in ln:
-            in_asm = False
-        elif in_asm and "v_mfma" in code:
-            n_mfma += 1
-        elif not in_asm and re.match(r"\s+(v_|ds_|global_|buffer_|scratch_|flat_)", code):
-            assert not re.search(r"\ba\[\d+:\d+\]|\ba\d+\b", code), f"compiler-generated AccVGPR access: {ln.strip()}"
-    assert n_mfma >= 32
+    errs, n = mod.audit(text)
+    assert n >= 4 and not errs, errs[:5]
+    bad = text.replace("#ASMEND", "#ASMEND\n\tv_accvgpr_read_b32 v1, a100", 1)
+    errs, _ = mod.audit(bad)
+    assert errs and "asm-owned AccVGPR" in errs[0]
+    assert "am_attention64.audit" in open(os.path.join(csrc, "Makefile")).read()
 

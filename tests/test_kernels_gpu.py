@@ -463,18 +463,3 @@ def test_f32_to_bf16(dev):
     x = _randn((1000003,), 1, dev) * 100
     assert torch.equal(ops.f32_to_bf16(x), x.to(torch.bfloat16))
 
-
-@pytest.mark.parametrize("M,N,K", [(4097, 1024, 1024), (2500, 3072, 512), (2304, 512, 64), (3000, 328, 192)])
-@pytest.mark.parametrize("mode", ["plain", "bias_gelu", "bias_res"])
-def test_gemm_4wave_matches_8wave(dev, M, N, K, mode):
-    """The hand-placed 4-wave main loop (am_gemm4w.hip, an A/B variant) and the 8-wave product kernel do the same arithmetic
-    in the same order per output element (k ascending in steps of 16, fp32 accumulation from the bias): bit-identical."""
-    from actionmesh_amd import ops
-    a = _randn((M, K), 1, dev).to(torch.bfloat16)
-    w = _randn((N, K), 2, dev, 1.0 / math.sqrt(K)).to(torch.bfloat16)
-    bias = rb(_randn((N,), 3, dev, 0.5)) if mode != "plain" else None
-    res = _randn((M, N), 4, dev).to(torch.bfloat16) if mode == "bias_res" else None
-    o8 = ops.gemm(a, w, bias=bias, residual=res, gelu=(mode == "bias_gelu"))
-    o4 = ops.gemm(a, w, bias=bias, residual=res, gelu=(mode == "bias_gelu"), use_4wave=True)
-    assert torch.equal(o4, o8)
-

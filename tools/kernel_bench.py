@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
     ap.add_argument("--ablate64", action="store_true", help="time the 4x64 kernel's ablations (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
+    ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
+    ap.add_argument("--blas", action="store_true", help="gemm: also time torch.matmul (hipBLASLt) on the same operands - the "
+                    "vendor library as a same-box reference point; never on the product path")
     a = ap.parse_args()
     T, N, C, H, S = (16, 4096, 1024, 8, 257) if a.shape == "headline" else (16, 2048, 2048, 16, 257)
     B, L = 2, N + 1
@@ -48,7 +51,7 @@ def main():
         fl = 4.0 * Sq * Sq * C * B
         for d, nm in ((a.defer, "product"), (a.defer + 60, "4x64 lazy"), (28, "4x64 exact"), (a.defer + 90, "8-wave"), (a.defer + 70, "balanced"), (a.defer + 50, "2x4-wave WGs"), (a.defer + 400, "lean64"), (a.defer + 200, "lockstep"), (a.defer + 300, "pipelined"),
                       (a.defer + 100, "staggered")):
-            if d >= 100 and not a.variants:
+            if (d >= 100 and not a.variants) or (a.product_only and nm != "product"):
                 continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:12s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
@@ -95,6 +98,10 @@ def main():
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
                                              force_small=small), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            if a.blas:
+                Wt = W.t()
+                ms = timeit(lambda: torch.matmul(A, Wt, out=out), a.reps)
+                print(f"gemm {name:13s} M={R} N={Nn} K={Kk} hipBLASLt(plain): {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             del A, W, out, res
     if "ln" in only:
         x = rnd(R, C); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)

@@ -24,6 +24,7 @@ constexpr int SMEM_MAIN = 2 * 2 * TILE_ELEMS * (int)sizeof(bf16_t);   // 73728
 constexpr int SMEM_EPI = BM * CS_LD * (int)sizeof(float);             // 67584
 constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
 constexpr int GROUP_M = 8;                    // m-tiles swept per pass over the W panels
+constexpr int B2 = 256;                       // tile edge of the 256x256 kernels
 
 __device__ inline int64_t map_row(int r, int G, int gs, int off) {
   if (G <= 0) return r;
@@ -192,6 +193,63 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
 }
 
 
+// Shared tail of the 256x256 kernels: the bf16 tile staged in LDS (row = 512 B, 8-byte unit u of row m at u ^ (m & 15))
+// goes out as row-contiguous 16-byte stores with the residual added on the way.
+__device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const unsigned char* stage, int tid, int m0, int n0) {
+  {
+    // thread -> 16-byte chunk k16 (8 columns) of rows ml = pass * 16 + (tid >> 5).  (ml & 15) does not depend on the pass,
+    // so the chunk sits at a fixed offset of its row and every per-pass LDS address is base + constant.
+    const int k16 = tid & 31, r16 = tid >> 5;
+    const int gn = n0 + k16 * 8;
+    if (gn < p.N) {
+      // the chunk's two 8-byte units; row r16 of each 16-row pass, +8192 B per pass
+      const unsigned char* su = stage + r16 * 512 + ((k16 ^ (r16 >> 1)) << 4);
+      const bool odd = r16 & 1;
+      auto fetch = [&](int pass) __attribute__((always_inline)) {
+        u32x4_t sv = *reinterpret_cast<const u32x4_t*>(su + pass * 8192);
+        if (odd) sv = u32x4_t{sv[2], sv[3], sv[0], sv[1]};
+        return sv;
+      };
+      auto add_res = [&](u32x4_t sv, const bf16_t* rp) __attribute__((always_inline)) {
+        const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(rp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
+        return sv;
+      };
+      if (p.c_G <= 0 && m0 + B2 <= p.M) {
+        // identity row map, full tile (every tile of the main grid at the reference shapes): rows advance by 16 * ldc per
+        // pass - wave-uniform base + one per-lane 32-bit offset, no per-pass address arithmetic, no bounds checks
+        const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
+        const int64_t step = (int64_t)16 * p.ldc;
+        bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
+        if (p.residual) {
+          const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
+#pragma unroll 4
+          for (int pass = 0; pass < 16; ++pass) {
+            const u32x4_t sv = add_res(fetch(pass), reinterpret_cast<const bf16_t*>(reinterpret_cast<const unsigned char*>(rrow + pass * step) + lane_off));
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = sv;
+          }
+        } else {
+#pragma unroll 4
+          for (int pass = 0; pass < 16; ++pass)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = fetch(pass);
+        }
+      } else {
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+          const int gmr = m0 + pass * 16 + r16;
+          if (gmr < p.M) {
+            u32x4_t sv = fetch(pass);
+            const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
+            if (p.residual) sv = add_res(sv, p.residual + pr * p.ldc + gn);
+            *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = sv;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ===========================================================================
 // v2: 256x256x64 tile, 8 waves (2 x 4, each 128 x 64), operands DMA'd straight
 // into LDS (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
@@ -204,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
 // Epilogue: bias/GELU in registers, bf16 tile staged through LDS (XOR-swizzled
 // 8-byte units), then row-contiguous 512-byte stores with the residual add.
 // ===========================================================================
-constexpr int B2 = 256;                        // BM = BN
 constexpr int T2_UNITS = B2 * (BK / 8);        // 16-byte units per operand tile (2048)
 constexpr int T2_BYTES = T2_UNITS * 16;        // 32 KiB
 constexpr int SMEM2_BYTES = 4 * T2_BYTES;      // A,B x 2 buffers = 128 KiB (epilogue reuses it)
@@ -359,59 +416,230 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
       }
     }
   __syncthreads();
-  {
-    // thread -> 16-byte chunk k16 (8 columns) of rows ml = pass * 16 + (tid >> 5).  (ml & 15) does not depend on the pass,
-    // so the chunk sits at a fixed offset of its row and every per-pass LDS address is base + constant.
-    const int k16 = tid & 31, r16 = tid >> 5;
-    const int gn = n0 + k16 * 8;
-    if (gn < p.N) {
-      // the chunk's two 8-byte units; row r16 of each 16-row pass, +8192 B per pass
-      const unsigned char* su = stage + r16 * 512 + ((k16 ^ (r16 >> 1)) << 4);
-      const bool odd = r16 & 1;
-      auto fetch = [&](int pass) __attribute__((always_inline)) {
-        u32x4_t sv = *reinterpret_cast<const u32x4_t*>(su + pass * 8192);
-        if (odd) sv = u32x4_t{sv[2], sv[3], sv[0], sv[1]};
-        return sv;
-      };
-      auto add_res = [&](u32x4_t sv, const bf16_t* rp) __attribute__((always_inline)) {
-        const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(rp);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
-        return sv;
-      };
-      if (p.c_G <= 0 && m0 + B2 <= p.M) {
-        // identity row map, full tile (every tile of the main grid at the reference shapes): rows advance by 16 * ldc per
-        // pass - wave-uniform base + one per-lane 32-bit offset, no per-pass address arithmetic, no bounds checks
-        const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
-        const int64_t step = (int64_t)16 * p.ldc;
-        bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
-        if (p.residual) {
-          const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
-#pragma unroll 4
-          for (int pass = 0; pass < 16; ++pass) {
-            const u32x4_t sv = add_res(fetch(pass), reinterpret_cast<const bf16_t*>(reinterpret_cast<const unsigned char*>(rrow + pass * step) + lane_off));
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = sv;
-          }
-        } else {
-#pragma unroll 4
-          for (int pass = 0; pass < 16; ++pass)
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = fetch(pass);
-        }
-      } else {
-#pragma unroll 2
-        for (int pass = 0; pass < 16; ++pass) {
-          const int gmr = m0 + pass * 16 + r16;
-          if (gmr < p.M) {
-            u32x4_t sv = fetch(pass);
-            const int64_t pr = map_row(gmr, p.c_G, p.c_gs, p.c_off);
-            if (p.residual) sv = add_res(sv, p.residual + pr * p.ldc + gn);
-            *reinterpret_cast<u32x4_t*>(p.C + pr * p.ldc + gn) = sv;
-          }
-        }
-      }
-    }
-  }
+  store_staged_tile(p, stage, tid, m0, n0);
 }
+
+
+// ===========================================================================
+// v3 "ping-pong" (round 2): the same 256x256x64 tile, LDS image and epilogue, a different main loop.
+//
+// The 8 waves are two groups of four (group g = tile rows [128 g, 128 g + 128); wave (g, wn) owns 128 x 64 outputs) that
+// run HALF A PHASE APART: group 1 executes one extra s_barrier before the loop, group 0 one after it, so between any two
+// consecutive barriers one group is in a pure-MFMA interval (16 x v_mfma_f32_16x16x32_bf16 = one 64 x 32 quadrant of its
+// tile over the whole 64-deep k-tile, s_setprio 1) while the other - its partner on every SIMD - is in its LDS interval
+// (fragment ds_read_b128s for its next quadrant + two LDS-DMA pieces of a later k-tile + the waits).  The matrix pipe of a
+// SIMD is therefore always fed by one wave while the other one fetches; in the round-1 loop both waves of a SIMD read,
+// waited and multiplied in lockstep and the pipe idled through every fetch (MFMA busy 42 %).
+//
+// k-tile t lives in LDS buffer t & 1 as four 16 KiB half-tiles [TA0 | TA1 | TB0 | TB1] (A rows 0-127 / 128-255, W rows
+// 0-127 / 128-255), each in the swizzled image of the v2 kernel (16-byte unit c of row r at c ^ ((r >> 1) & 7); conflict
+// free for the 16x16x32 fragment pattern row = lane & 15, unit = lane >> 4 as well).  Group g reads TA_g only; W fragments
+// of a tile are read in its first two intervals, A fragments in the first and third, so
+//     interval     R1            R2            R3             R4
+//     reads        a0 (8) b0 (4) b1 (4)        a1 (8)         -
+//     stages       TA0(t+1)      TA1(t+1)      TB0(t+2)       TB1(t+2)   then s_waitcnt vmcnt(4)
+//     multiplies   M1: a0 x b0   M2: a0 x b1   M3: a1 x b1    M4: a1 x b0
+// (TA(t+1) goes to the other buffer, whose last A reads were in tile t-1's R3; TB(t+2) goes to THIS buffer, whose W
+// reads ended in R2: every wave drains its LDS reads - lgkmcnt(0) - in front of the barrier that ends an R interval, so
+// a DMA issued after that barrier cannot overtake them.)  The LDS-DMA queue is never drained inside the loop: the one
+// counted wait per k-tile, vmcnt(4) at the end of R4, leaves the two newest stages (TB(t+2)) in flight and retires
+// everything tile t+1 needs, a full k-tile after it was issued; the barrier behind it publishes it to both groups.
+// Past the end of K the stages re-fetch the last tile into slots nobody reads, so the counts stay constant.
+// ===========================================================================
+constexpr int HT_BYTES = 128 * BK * 2;         // one half-tile (16 KiB)
+constexpr int PBUF_BYTES = 4 * HT_BYTES;       // [TA0 | TA1 | TB0 | TB1] (64 KiB); two buffers = 128 KiB
+
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n, int m_base) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int nb = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  int lid;
+  {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = lid / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    const int in_g = lid - g * group_sz;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+  }
+  const int m0 = m_base + tm * B2, n0 = tn * B2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;           // wm = group
+
+  // ---- accumulators start from the bias.  D = Wfrag x Afrag: lane (l & 15, l >> 4) of block (mi, ni) holds output row
+  // m = mi*16 + (l & 15), columns n = ni*16 + (l >> 4)*4 .. +3.  The bias is fetched and waited for BEFORE the first LDS-DMA
+  // goes out: hipcc waits vmcnt(0) at the use of an ordinary load, which would drain the whole prologue otherwise.
+  const int l15 = lane & 15, l4 = lane >> 4;
+  f32x4_t acc[8][4];
+  {
+    f32x4_t bv[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      bv[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bv[ni] = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + wn * 64 + ni * 16 + l4 * 4, p.N - 4));
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(bv[ni]));
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = bv[ni];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- LDS-DMA sources, in 16-byte units from the operand base (32 bits reach 64 GiB).  Piece pc of half-tile h covers
+  // rows pc*64 + wave*8 + (lane >> 3) of the half; the lane fetches the unit that belongs at its lane-linear LDS slot.
+  uint32_t offA1[4], offA2[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int half = i >> 1, pc = i & 1;
+    const int r = pc * 64 + wave * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int ar = min(m0 + half * 128 + r, p.M - 1);
+    const int64_t pr = map_row(ar, p.a_G, p.a_gs, p.a_off);
+    offA1[i] = (uint32_t)(pr * (p.lda1 >> 3) + c);
+    offA2[i] = (uint32_t)(pr * (p.lda2 >> 3) + c);
+    const int wr = min(n0 + half * 128 + r, p.N - 1);
+    offW[i] = (uint32_t)((int64_t)wr * (p.ldw >> 3) + c);
+  }
+  auto stage_a = [&](int half, int kt, int buf_off) __attribute__((always_inline)) {
+    const int k0 = kt * BK;
+    const bool first = k0 < p.K1;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(first ? p.A1 + k0 : p.A2 + (k0 - p.K1));
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const uint32_t off = first ? offA1[half * 2 + pc] : offA2[half * 2 + pc];
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + ((uint64_t)off << 4)),
+                                       (lds_ptr_t)(smem + buf_off + half * HT_BYTES + (pc * 512 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  auto stage_w = [&](int half, int kt, int buf_off) __attribute__((always_inline)) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(p.W + kt * BK);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + ((uint64_t)offW[half * 2 + pc] << 4)),
+                                       (lds_ptr_t)(smem + buf_off + (2 + half) * HT_BYTES + (pc * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+
+
+  // ---- fragment addresses: row = block row + (l & 15), 16-byte unit (ks*4 + (l >> 4)) ^ ((row >> 1) & 7); block rows are
+  // multiples of 16, so the swizzle term is the lane's own ((l & 15) >> 1)
+  const int fo0 = l15 * 128 + (((0 + l4) ^ (l15 >> 1)) << 4);
+  const int fo1 = l15 * 128 + (((4 + l4) ^ (l15 >> 1)) << 4);
+  const int a_base = wm * HT_BYTES;
+  const int w_base = (2 + (wn >> 1)) * HT_BYTES + (wn & 1) * 64 * 128;
+
+  bf16x8_t af[4][2], wf[4][2];
+  auto read_a = [&](int cur, int mh) __attribute__((always_inline)) {        // rows mh*64 .. +64 of the wave's 128
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned char* q = smem + cur + a_base + (mh * 4 + i) * 2048;
+      af[i][0] = *reinterpret_cast<const bf16x8_t*>(q + fo0);
+      af[i][1] = *reinterpret_cast<const bf16x8_t*>(q + fo1);
+    }
+  };
+  auto read_w = [&](int cur, int nh) __attribute__((always_inline)) {        // columns nh*32 .. +32 of the wave's 64
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* q = smem + cur + w_base + (nh * 2 + j) * 2048;
+      wf[nh * 2 + j][0] = *reinterpret_cast<const bf16x8_t*>(q + fo0);
+      wf[nh * 2 + j][1] = *reinterpret_cast<const bf16x8_t*>(q + fo1);
+    }
+  };
+  // one quadrant: 4 row blocks x 2 column blocks x 2 k-steps; the two k-steps of a block are 8 MFMAs apart
+#define PP_QUADRANT(MH, NH)                                                                                       \
+  do {                                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+          acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                              \
+              wf[(NH) * 2 + j][ks], af[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);                         \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+  } while (0)
+
+  const int nk = p.K / BK;
+  // prologue: tile 0 and the W halves of tile 1
+  stage_a(0, 0, 0); stage_a(1, 0, 0); stage_w(0, 0, 0); stage_w(1, 0, 0);
+  {
+    const int t1 = min(1, nk - 1);
+    stage_w(0, t1, PBUF_BYTES); stage_w(1, t1, PBUF_BYTES);
+  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();                       // group 1 runs one interval behind group 0
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = (t & 1) * PBUF_BYTES, nxt = PBUF_BYTES - cur;
+    const int ta = min(t + 1, nk - 1), tb = min(t + 2, nk - 1);
+    // R1 / M1
+    read_a(cur, 0); read_w(cur, 0);
+    stage_a(0, ta, nxt);
+    PP_LGKM0(); PP_BARRIER();
+    PP_QUADRANT(0, 0);
+    PP_BARRIER();
+    // R2 / M2
+    read_w(cur, 1);
+    stage_a(1, ta, nxt);
+    PP_LGKM0(); PP_BARRIER();
+    PP_QUADRANT(0, 1);
+    PP_BARRIER();
+    // R3 / M3
+    read_a(cur, 1);
+    stage_w(0, tb, cur);
+    PP_LGKM0(); PP_BARRIER();
+    PP_QUADRANT(1, 1);
+    PP_BARRIER();
+    // R4 / M4
+    stage_w(1, tb, cur);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // everything tile t+1 needs has landed (this wave's share)
+    PP_BARRIER();
+    PP_QUADRANT(1, 0);
+    PP_BARRIER();
+  }
+  if (wm == 0) PP_BARRIER();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing re-fetches must not land on the C staging below
+  PP_BARRIER();
+
+  // ---- epilogue: bf16 tile staged through LDS (row = 512 B = 64 units of 8 B, unit u of row m at u ^ (m & 15)), then the
+  // row-contiguous store loop of the v2 kernel ------------------------------------------------------------------------
+  unsigned char* stage = smem;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int ml = wm * 128 + mi * 16 + l15;
+      const int nl = wn * 64 + ni * 16 + l4 * 4;               // 4 consecutive columns
+      u32x2_t w;
+      if (p.act == 1) {                                        // F.gelu on the bf16 linear output -> bf16
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(acc[mi][ni][e]));
+        w = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      } else {
+        w = u32x2_t{pack_bf2(acc[mi][ni][0], acc[mi][ni][1]), pack_bf2(acc[mi][ni][2], acc[mi][ni][3])};
+      }
+      const int u = (nl >> 2) ^ (ml & 15);
+      *reinterpret_cast<u32x2_t*>(stage + ml * 512 + u * 8) = w;
+    }
+  __syncthreads();
+  store_staged_tile(p, stage, tid, m0, n0);
+}
+#undef PP_QUADRANT
 
 }  // namespace
 
@@ -433,17 +661,22 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
     attr_set = true;
   }
-  // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings)
+  // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings); bit 9 (0x200) the round-1
+  // lockstep main loop of the 256x256 tile (same-box A/B against the ping-pong loop)
   am_gemm_args args = *a;
   const bool force_small = (args.act & 0x100) != 0;
+  const bool legacy = (args.act & 0x200) != 0;
+  const bool force_big = (args.act & 0x400) != 0;       // tests: the 256x256 tile whatever the grid size
   args.act &= 0xff;
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
   // the 256x256 tiles need a grid that fills the 256 CUs; mid-sized problems (the context encoder's 16 x 257 rows)
   // get four times as many 128x128 workgroups instead
-  const bool big = !force_small && args.N >= 256 && args.M >= 1024 &&
-                   (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192;
+  const bool big = !force_small && args.N >= 8 && args.M >= 1 &&
+                   (force_big || (args.N >= 256 && args.M >= 1024 && (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192));
   if (big) {
     // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
     // frame): a last 256-row tile holding a few rows would cost a whole extra round of workgroups.
@@ -451,8 +684,12 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
     const int rem = args.M % B2;
     const int m_main = (rem != 0 && rem <= 128 && args.M > 8 * B2) ? args.M - rem : args.M;
     const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
-    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
-                       (hipStream_t)stream, args, tiles_m, tiles_n, 0);
+    if (legacy)
+      hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
+                         (hipStream_t)stream, args, tiles_m, tiles_n, 0);
+    else
+      hipLaunchKernelGGL(gemm256pp_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
+                         (hipStream_t)stream, args, tiles_m, tiles_n, 0);
     if (m_main < args.M) {
       const int tn = ceil_div(args.N, BN);
       hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);

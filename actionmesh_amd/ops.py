@@ -57,7 +57,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, gelu: bool = False,
          a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
-         M: Optional[int] = None, force_small: bool = False) -> torch.Tensor:
+         M: Optional[int] = None, force_small: bool = False, legacy: bool = False,
+         force_big: bool = False) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
@@ -84,8 +85,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.residual = _p(_need(residual, torch.bfloat16, "residual")) if residual is not None else None
     g.C = out.data_ptr(); g.ldc = out.stride(0)
     g.M, g.N, g.K = M, N, K
-    # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings)
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0)
+    # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings);
+    # 0x200: the round-1 lockstep main loop of the 256x256 tile (same-box A/B); 0x400: the 256x256 tile at any grid size (tests)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
     _launch(a, L.lib().am_gemm_bf16, "am_gemm_bf16", C.byref(g))

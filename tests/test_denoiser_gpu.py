@@ -60,7 +60,8 @@ def test_forward_matches_reference_fixture_and_oracle(dev, golden_dir, name):
     cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
     x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
     tt = torch.tensor([float(g["fwd_t"])]).expand(2)
-    v, cache = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+    c_dev = c_in.to(dev)
+    v, cache = model.forward(x_in.to(dev), c_dev, f_in.to(dev), tt.to(dev), m_in.to(dev), None)
     torch.cuda.synchronize()
     assert v.shape == x_in.shape and v.dtype == torch.bfloat16
     v = v.float().cpu()
@@ -69,9 +70,12 @@ def test_forward_matches_reference_fixture_and_oracle(dev, golden_dir, name):
     r32, rbf = rel(v, ref32), rel(v, vb)
     print(f"{name}: forward rel-L2 vs reference fp32 {r32:.3e}, vs bf16-policy oracle {rbf:.3e}")
     assert r32 < 2e-2 and rbf < 1.5e-2
-    # passing the returned cache back reuses the bound window and gives the identical result
-    v2, cache2 = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), cache)
+    # passing the returned cache back with the SAME context tensor reuses the bound window and gives the identical result;
+    # another tensor (even with equal values) re-binds: the cache follows the context, not the cache object
+    v2, cache2 = model.forward(x_in.to(dev), c_dev, f_in.to(dev), tt.to(dev), m_in.to(dev), cache)
     assert cache2 is cache and torch.equal(v2.float().cpu(), v)
+    v3, cache3 = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), cache)
+    assert cache3 is not cache and torch.equal(v3.float().cpu(), v)
 
 
 @pytest.mark.parametrize("name", list(CASES))

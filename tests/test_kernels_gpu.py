@@ -110,7 +110,7 @@ def test_gemm256_split_a_row_maps_and_tails(dev):
     bias = rb(_randn((N,), 4, dev, 0.5))
     res = _randn((frames * L, N), 5, dev).to(torch.bfloat16)
     dst = res.clone()
-    ops.gemm(a1, w, bias=bias, a2=a2, residual=dst, out=dst, a_map=(G, L, 1), c_map=(G, L, 1), M=M)
+    ops.gemm(a1, w, bias=bias, a2=a2, residual=dst, out=dst, a_map=(G, L, 1), c_map=(G, L, 1), M=M, force_big=True)
     torch.cuda.synchronize()
     cat = torch.cat([a1, a2], 1).view(frames, L, K1 + K2)[:, 1:].reshape(M, K1 + K2).float()
     lin = rb(cat @ w.float().T + bias)
@@ -119,6 +119,38 @@ def test_gemm256_split_a_row_maps_and_tails(dev):
     got = dst.view(frames, L, N)
     _close(got[:, 1:], ref, atol=4e-3, what="gemm256 maps", mag=torch.maximum(lin.view(frames, G, N).abs(), r3[:, 1:].abs()))
     assert torch.equal(got[:, 0], res.view(frames, L, N)[:, 0]), "row 0 of every frame must be untouched"
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 64), (1300, 256, 128), (777, 328, 192), (4097, 1024, 1024), (2500, 3072, 512),
+                                   (256, 256, 4096), (5000, 520, 320)])
+@pytest.mark.parametrize("mode", ["plain", "bias_gelu", "bias_res"])
+def test_gemm256_pingpong_main_loop(dev, M, N, K, mode):
+    """The 256x256 tile with the two-group ping-pong main loop (the product path of every large linear), forced at modest
+    grid sizes: 1 .. 64 k-tiles (prologue / steady state / clamped tail stages), M and N tails, every epilogue.  Against the
+    fp32 statement (<= 2 bf16 ulp) and against the round-1 lockstep loop on the same tile (the same products summed in a
+    different MFMA shape: 16x16x32 vs 32x32x16 - equal up to fp32 summation order, i.e. <= 1 bf16 ulp of the linear)."""
+    from actionmesh_amd import ops
+    a = _randn((M, K), 1, dev).to(torch.bfloat16)
+    w = _randn((N, K), 2, dev, 1.0 / math.sqrt(K)).to(torch.bfloat16)
+    bias = rb(_randn((N,), 3, dev, 0.5)) if mode != "plain" else None
+    res = _randn((M, N), 4, dev).to(torch.bfloat16) if mode == "bias_res" else None
+    kw = dict(bias=bias, residual=res, gelu=(mode == "bias_gelu"))
+    out = ops.gemm(a, w, force_big=True, **kw)
+    old = ops.gemm(a, w, force_big=True, legacy=True, **kw)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T
+    if bias is not None:
+        ref = ref + bias
+    ref = rb(ref)
+    mag = ref.abs()
+    if mode == "bias_gelu":
+        ref = rb(F.gelu(ref))
+    if res is not None:
+        mag = torch.maximum(mag, res.float().abs())
+        ref = ref + res.float()
+    _close(out, ref, ulps=2.0, atol=2e-3 * math.sqrt(K / 64), what=f"gemm256pp {M}x{N}x{K} {mode}", mag=mag)
+    _close(out, old.float(), ulps=1.0, atol=1e-3 * math.sqrt(K / 64), what=f"gemm256pp vs lockstep {M}x{N}x{K} {mode}", mag=mag)
+    assert torch.equal(out, ops.gemm(a, w, force_big=True, **kw)), "run-to-run bits"
 
 
 def test_gemm_in_place_residual(dev):

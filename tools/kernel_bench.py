@@ -94,9 +94,9 @@ def main():
             A = rnd(R, Kk); W = rnd(Nn, Kk); out = torch.empty((R, Nn), dtype=torch.bfloat16, device=dev)
             bias = torch.randn(Nn, device=dev) if kw.get("bias") else None
             res = rnd(R, Nn) if kw.get("res") else None
-            for small, nm in ((False, "256sq         "), (True, "128sq-regstage")):
+            for small, leg, nm in ((False, False, "256sq-pingpong"), (False, True, "256sq-lockstep"), (True, False, "128sq-regstage")):
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
-                                             force_small=small), a.reps)
+                                             force_small=small, legacy=leg), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             if a.blas:
                 Wt = W.t()

@@ -27,7 +27,7 @@ class AmConfig(C.Structure):
         ("inflated_mask_lo", C.c_uint32), ("inflated_mask_hi", C.c_uint32),
         ("max_batch", C.c_int32), ("max_frames_local", C.c_int32), ("max_tokens", C.c_int32),
         ("max_ctx_tokens", C.c_int32), ("world_size", C.c_int32), ("rank", C.c_int32),
-        ("attn_defer_log2", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("attn_defer_log2", C.c_int32), ("attn_fp8", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -96,6 +96,8 @@ SYMBOLS = {
     "am_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "am_head_post": (C.c_int, [C.POINTER(AmHeadPostArgs), _P]),
     "am_attention_bf16": (C.c_int, [C.POINTER(AmAttnArgs), _P]),
+    "am_attention_quantize_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
+    "am_attention_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
     "am_f32_to_bf16": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

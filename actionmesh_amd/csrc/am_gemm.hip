@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);       // nn.Linear result in bf16
-        if (p.act == 1) {
+        if ((p.act & 0xff) == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = rbf(gelu_erf(v[e]));   // F.gelu on bf16 -> bf16
         }
@@ -216,13 +216,19 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
         for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
         return sv;
       };
-      if (p.c_G <= 0 && m0 + B2 <= p.M) {
+      const bool abl_nostore = (p.act & 0x800) != 0, abl_nores = (p.act & 0x1000) != 0;   // timing ablations (tools/kernel_bench.py)
+      if (abl_nostore) {
+        u32x4_t keep = fetch(0);
+#pragma unroll 4
+        for (int pass = 1; pass < 16; ++pass) { const u32x4_t f = fetch(pass); keep[0] ^= f[0] ^ f[3]; }
+        if (keep[0] == 0x12345678u && p.M < 0) *reinterpret_cast<u32x4_t*>(p.C) = keep;          // never true: keeps the reads live
+      } else if (p.c_G <= 0 && m0 + B2 <= p.M) {
         // identity row map, full tile (every tile of the main grid at the reference shapes): rows advance by 16 * ldc per
         // pass - wave-uniform base + one per-lane 32-bit offset, no per-pass address arithmetic, no bounds checks
         const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
         const int64_t step = (int64_t)16 * p.ldc;
         bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
-        if (p.residual) {
+        if (p.residual && !abl_nores) {
           const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
 #pragma unroll 4
           for (int pass = 0; pass < 16; ++pass) {
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
       for (int i = 0; i < 4; ++i) {
         const int ml = wm * 128 + i * 32 + l31;
         u32x2_t w;
-        if (p.act == 1) {                                        // F.gelu on the bf16 linear output -> bf16
+        if ((p.act & 0xff) == 1) {                               // F.gelu on the bf16 linear output -> bf16
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(acc[i][j][4 * g + e]));
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
       const int ml = wm * 128 + mi * 16 + l15;
       const int nl = wn * 64 + ni * 16 + l4 * 4;               // 4 consecutive columns
       u32x2_t w;
-      if (p.act == 1) {                                        // F.gelu on the bf16 linear output -> bf16
+      if ((p.act & 0xff) == 1) {                               // F.gelu on the bf16 linear output -> bf16
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(rbf(acc[mi][ni][e]));
@@ -671,12 +677,14 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   const bool force_small = (args.act & 0x100) != 0;
   const bool legacy = (args.act & 0x200) != 0;
   const bool force_big = (args.act & 0x400) != 0;       // tests: the 256x256 tile whatever the grid size
+  const int abl = args.act & 0x1800;
   args.act &= 0xff;
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
   // the 256x256 tiles need a grid that fills the 256 CUs; mid-sized problems (the context encoder's 16 x 257 rows)
   // get four times as many 128x128 workgroups instead
   const bool big = !force_small && args.N >= 8 && args.M >= 1 &&
                    (force_big || (args.N >= 256 && args.M >= 1024 && (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192));
+  args.act |= abl;          // kernels test `act & 0xff`; bits 11 / 12 are the store / residual timing ablations
   if (big) {
     // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
     // frame): a last 256-row tile holding a few rows would cost a whole extra round of workgroups.

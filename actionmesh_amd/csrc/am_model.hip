@@ -44,6 +44,7 @@ struct am_model {
   bf16_t *hwork = nullptr, *z = nullptr, *ao = nullptr, *qkv = nullptr, *ffh = nullptr;
   std::vector<bf16_t*> skip;
   bf16_t *Qb = nullptr, *Kg = nullptr, *Vtg = nullptr;
+  uint8_t *Q8 = nullptr, *K8 = nullptr, *Vt8 = nullptr;   // fp8 operand copies (cfg.attn_fp8)
   bool kv_external = false;
   size_t chunk_elems = 0;
   size_t chunk_stride = 0;     // elements between consecutive ranks' K (or V^T) chunks
@@ -195,6 +196,7 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
   AM_CHECK(cfg->world_size >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world_size, "am_create: rank %d / world %d",
            cfg->rank, cfg->world_size);
   AM_CHECK(cfg->attn_defer_log2 == 0 || cfg->attn_defer_log2 == 8, "am_create: attn_defer_log2 must be 0 or 8");
+  AM_CHECK(cfg->attn_fp8 == 0 || cfg->attn_fp8 == 1, "am_create: attn_fp8 must be 0 or 1");
   int ndev = 0;
   AM_HIP(hipGetDeviceCount(&ndev));
   AM_CHECK(ndev > 0, "am_create: no HIP device visible (this library has no CPU path)");
@@ -325,9 +327,16 @@ extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev
 }
 
 static int ensure_kv(am_model* m) {
-  if (m->Kg) return AM_OK;
-  AM_TRY(dev_alloc_t(m, &m->Kg, m->chunk_elems * (size_t)m->P));
-  AM_TRY(dev_alloc_t(m, &m->Vtg, m->chunk_elems * (size_t)m->P));
+  if (!m->Kg) {
+    AM_TRY(dev_alloc_t(m, &m->Kg, m->chunk_elems * (size_t)m->P));
+    AM_TRY(dev_alloc_t(m, &m->Vtg, m->chunk_elems * (size_t)m->P));
+  }
+  if (m->cfg.attn_fp8 && !m->K8) {
+    const size_t q_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 256) * HD;
+    AM_TRY(dev_alloc_t(m, &m->Q8, q_inf));
+    AM_TRY(dev_alloc_t(m, &m->K8, m->chunk_stride * (size_t)m->P));
+    AM_TRY(dev_alloc_t(m, &m->Vt8, m->chunk_stride * (size_t)m->P));
+  }
   return AM_OK;
 }
 
@@ -487,7 +496,12 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       at.nseq = h->B * h->T; at.sq = L; at.sq_pad = pad_to(L, 256);
       at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
     }
-    AM_TRY(am_attention_bf16(&at, st));
+    if (h->cfg.attn_fp8 && h->inflated(i)) {       // fp8 variant of the long-key-stream attention (configs[4])
+      AM_TRY(am_attention_quantize_fp8(&at, h->Q8, h->K8, h->Vt8, st));
+      AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
+    } else {
+      AM_TRY(am_attention_bf16(&at, st));
+    }
   }
   AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, R, C, C, 0));   // to_out + residual (block.py:137)
   h->hsrc = h->hwork;

@@ -78,7 +78,7 @@ class HipEngine:
 
     def __init__(self, hp: Dict, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  max_batch: int, frames_local: int, tokens: int, ctx_tokens: int,
-                 world: int = 1, rank: int = 0, attn_defer_log2: int = 8):
+                 world: int = 1, rank: int = 0, attn_defer_log2: int = 8, attn_dtype: str = "bf16"):
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -99,6 +99,9 @@ class HipEngine:
         cfg.max_batch, cfg.max_frames_local, cfg.max_tokens, cfg.max_ctx_tokens = self.bounds
         cfg.world_size, cfg.rank = world, rank
         cfg.attn_defer_log2 = attn_defer_log2
+        if attn_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"attn_dtype must be 'bf16' or 'fp8', got {attn_dtype!r}")
+        cfg.attn_fp8 = 1 if attn_dtype == "fp8" else 0
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self.lib.am_create(C.byref(cfg), C.byref(self.handle)), "am_create")
@@ -216,8 +219,9 @@ class HipDenoiser(nn.Module):
                  inflated_layers: Optional[Sequence[int]] = None, clear_autocast: bool = True,
                  compile_blocks: bool = False, compile_mode: str = "default",
                  process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8,
-                 cfg_parallel: bool = True):
+                 cfg_parallel: bool = True, attn_dtype: str = "bf16"):
         super().__init__()
+        self.attn_dtype = attn_dtype        # "fp8": inflated self-attention on the e4m3 MFMA kernel (BASELINE configs[4])
         if width != num_attention_heads * HEAD_DIM:
             raise ValueError("HipDenoiser supports head_dim 128 only (width = heads * 128), as the reference ships")
         self.num_tokens_nominal = num_tokens_nominal
@@ -302,7 +306,8 @@ class HipDenoiser(nn.Module):
         if e is not None:
             e.close()
         self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
-                                 world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2)
+                                 world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2,
+                                 attn_dtype=self.attn_dtype)
         self._window = None
         return self._engine
 

@@ -58,7 +58,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
          M: Optional[int] = None, force_small: bool = False, legacy: bool = False,
-         force_big: bool = False) -> torch.Tensor:
+         force_big: bool = False, ablate: int = 0) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
@@ -87,7 +87,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.M, g.N, g.K = M, N, K
     # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings);
     # 0x200: the round-1 lockstep main loop of the 256x256 tile (same-box A/B); 0x400: the 256x256 tile at any grid size (tests)
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0x1800)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
     _launch(a, L.lib().am_gemm_bf16, "am_gemm_bf16", C.byref(g))
@@ -174,6 +174,36 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
         assert state.numel() >= nseq * H * sq_pad * STATE_LD
         a.state = state.data_ptr()
     _launch(q, L.lib().am_attention_bf16, "am_attention_bf16", C.byref(a))
+    return out
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: int,
+                  out: Optional[torch.Tensor] = None, nchunks: int = 1, scale: Optional[float] = None,
+                  quantized: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, **_ignored) -> torch.Tensor:
+    """fp8 (e4m3) attention on the bf16 operand layouts of `attention`: quantise (unless `quantized` = (q8, k8, vt8) from an
+    earlier call is passed), then QK^T / P.V on the MX-scaled fp8 MFMA.  Returns out (nseq * sq, H * 128) bf16."""
+    _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
+    nseq, H, sq_pad, _ = q.shape
+    sk_pad = k.shape[-2]
+    if out is None:
+        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=torch.bfloat16, device=q.device)
+    a = L.AmAttnArgs()
+    a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = nseq, H, sq, sq_pad, sk, sk_pad
+    a.nchunks = nchunks
+    a.chunk_stride = nseq * H * sk_pad * HEAD_DIM
+    a.ldo = out.stride(0)
+    a.scale = scale if scale is not None else HEAD_DIM ** -0.5
+    if quantized is None:
+        q8 = torch.empty(q.shape, dtype=torch.uint8, device=q.device)
+        k8 = torch.empty(k.shape, dtype=torch.uint8, device=q.device)
+        vt8 = torch.empty(vt.shape, dtype=torch.uint8, device=q.device)
+        _launch(q, L.lib().am_attention_quantize_fp8, "am_attention_quantize_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(),
+                vt8.data_ptr())
+    else:
+        q8, k8, vt8 = quantized
+    _launch(q, L.lib().am_attention_fp8, "am_attention_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr())
+    attention_fp8.last_quantized = (q8, k8, vt8)
     return out
 
 

@@ -68,7 +68,8 @@ typedef struct {
   int32_t world_size;           /* frame-shard degree P (1 = single GPU) */
   int32_t rank;                 /* this rank's shard index */
   int32_t attn_defer_log2;      /* online-softmax deferred-rescale threshold (log2 units); 0 = always rescale */
-  int32_t reserved[7];
+  int32_t attn_fp8;             /* 1 = inflated self-attention on the fp8 kernel (am_attention_fp8); 0 = bf16 (default) */
+  int32_t reserved[6];
 } am_config;
 
 typedef struct am_model* am_handle;
@@ -214,6 +215,14 @@ int am_attention_bf16(const am_attn_args* args, void* stream);
  * a workgroup that meets a single-tile jump of more than 2^60 is recomputed by an exact kernel launched behind it.
  * Returns how many workgroups that fallback has recomputed on the current device so far (synchronises the device). */
 int am_attention_fallback_count(uint64_t* count);
+
+/* fp8 (OCP e4m3) variant of the same attention (BASELINE.json configs[4]: "fp8 MFMA"): QK^T and P.V on the MX-scaled
+ * K = 64 MFMA (block scales 2^0), fp32 online softmax, bf16 output.  Two calls: quantise the bf16 operand layouts that
+ * am_head_post writes (Q pre-multiplied by scale * log2 e; V^T re-ordered to the key order of the fp8 P.V operand), then
+ * attend.  q8 / k8 / vt8 have the element counts and strides of Q / K / Vt (one byte per element; chunk_stride counts
+ * bytes).  The one-pass form only (rows = 0, state_mode = 0).  Stated tolerance vs fp32 SDPA: tests/test_attention_fp8.py. */
+int am_attention_quantize_fp8(const am_attn_args* args, uint8_t* q8, uint8_t* k8, uint8_t* vt8, void* stream);
+int am_attention_fp8(const am_attn_args* args, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8, void* stream);
 
 /* small fused elementwise ops */
 int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream);

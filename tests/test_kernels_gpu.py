@@ -149,7 +149,9 @@ def test_gemm256_pingpong_main_loop(dev, M, N, K, mode):
         mag = torch.maximum(mag, res.float().abs())
         ref = ref + res.float()
     _close(out, ref, ulps=2.0, atol=2e-3 * math.sqrt(K / 64), what=f"gemm256pp {M}x{N}x{K} {mode}", mag=mag)
-    _close(out, old.float(), ulps=1.0, atol=1e-3 * math.sqrt(K / 64), what=f"gemm256pp vs lockstep {M}x{N}x{K} {mode}", mag=mag)
+    # GELU is evaluated on the bf16-rounded linear: a 1-ulp difference of the linear moves the activation by up to 1 ulp of ITS input
+    _close(out, old.float(), ulps=2.0 if mode == "bias_gelu" else 1.0, atol=1e-3 * math.sqrt(K / 64),
+           what=f"gemm256pp vs lockstep {M}x{N}x{K} {mode}", mag=mag)
     assert torch.equal(out, ops.gemm(a, w, force_big=True, **kw)), "run-to-run bits"
 
 

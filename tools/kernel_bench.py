@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
     ap.add_argument("--ablate64", action="store_true", help="time the 4x64 kernel's ablations (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
+    ap.add_argument("--ablate-gemm", action="store_true", help="gemm: time the epilogue ablations (no C stores / no residual loads)")
     ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
     ap.add_argument("--blas", action="store_true", help="gemm: also time torch.matmul (hipBLASLt) on the same operands - the "
                     "vendor library as a same-box reference point; never on the product path")
@@ -55,6 +56,12 @@ def main():
                 continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:12s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if not a.product_only:
+            ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out), a.reps)
+            print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (quantise + attend)  : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+            qz = ops.attention_fp8.last_quantized
+            ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz), a.reps)
+            print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (attend only)        : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         if a.ablate64:
             for k, nm in {1: "no exp", 2: "no row max", 4: "no barrier / DMA drain", 8: "no exp/sum/pack", 10: "no softmax VALU",
                           14: "no softmax VALU, no barrier", 16: "no LDS fragment addressing (same stage)", 30: "MFMA + fragment reads only", 32: "no exp/sum/pack beside P.V (phase 1b)", 64: "no exp/sum/pack beside QK^T (phase 2b)", 128: "no LDS fragment reads", 132: "no LDS reads, no barrier",
@@ -98,6 +105,10 @@ def main():
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
                                              force_small=small, legacy=leg), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            if a.ablate_gemm:
+                for ab, nm in ((0x800, "no C stores"), (0x1000, "no residual loads"), (0x1800, "neither")):
+                    ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out, ablate=ab), a.reps)
+                    print(f"  gemm {name:13s} ablation {nm:18s}: {ms:8.3f} ms")
             if a.blas:
                 Wt = W.t()
                 ms = timeit(lambda: torch.matmul(A, Wt, out=out), a.reps)

@@ -23,7 +23,12 @@
 // packing per lane, plus the fragment ds_reads and LDS-DMA issue for its next matrix interval).  K8 / V8T tiles (8 + 8 KiB
 // per 64 keys) arrive by LDS-DMA into a 4-deep ring, three tiles ahead, retired by one counted vmcnt(2) per tile.
 // Online softmax with a deferred re-base (threshold 2^3): p = 2^(s - m_run + 5), so p <= 2^8 fits e4m3 (max 448) and
-// probabilities down to 2^-14 of the row maximum survive the 2^-9 flush; the row sums are taken in fp32 before rounding.
+// probabilities down to 2^-14 of the row maximum survive the 2^-9 flush.  The VALU interval is what bounds this kernel, so
+// it carries only what has to be there - 32 exp2, 16 packs, 11 max3 per lane and tile: the scores are born relative to the
+// running max (the QK^T accumulators start from a splat of 5 - m_run: no subtraction in front of the exponentials), and keys
+// past a chunk's end are a wave-uniform branch taken once per chunk; fragment reads and LDS-DMA issue sit in the matrix
+// interval, between MFMAs, where the wave only waits for the pipe.  (Row sums on the matrix pipe - one more MFMA against a
+// block of ones - were written and dropped: 24 more registers, and at 256 the kernel spills.)
 #include "am_common.h"
 
 namespace {
@@ -35,7 +40,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int HD8 = 128;
 constexpr int KT = 64;                 // keys per tile
 constexpr int STAGE_BYTES = 16384;     // K8 tile [64][128] + V8T tile [128][64]
-constexpr int NSTAGE = 4;
+constexpr int NSTAGE = 8;             // ring slots (tiles are staged five ahead)
 constexpr float P_SHIFT = 5.f;         // probabilities are carried as 2^5 p (row sums too: the factor cancels in O / l)
 constexpr float DEFER_T = 3.f;         // deferred re-base threshold (log2 units)
 constexpr int SCALE_ONE = 0x7f7f7f7f;  // E8M0 block scale 2^0
@@ -46,6 +51,30 @@ __device__ inline float clamp_e4m3(float x) { return fminf(fmaxf(x, -448.f), 448
 __host__ __device__ inline int kperm(int pos) {
   const int h = pos >> 5, j = pos & 31;
   return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
+}
+
+// Value of the same register in lane ^ 32 (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second).
+// hipcc (ROCm 7.2) FOLDS arithmetic on the two results when both operands are one SSA value - fmaxf(sw[0], sw[1]) becomes
+// sw[0] and sw[0] + sw[1] becomes 2 sw[0], although the results differ in every lane (measured: row sums of the softmax off
+// by the ratio of the two half-row sums).  Making one operand opaque stops the fold; the partner's value is then selected
+// by lane half and combined with the lane's own value explicitly.
+__device__ inline float other_half(float x, int hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("" : "+v"(b));
+  const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return __builtin_bit_cast(float, hi ? sw[0] : sw[1]);
+}
+
+// The MFMAs of the main loop are inline asm: a builtin MFMA is a pure value to the IR passes, which sink it below the
+// fragment reads that are meant to REUSE its operand registers (both fragment sets live at once: spills at 256 VGPRs and a
+// vmcnt(0) in front of every reload).  asm volatile statements keep their order among themselves and, with the "memory"
+// clobber, against the LDS reads / LDS-DMA around them.  hipcc pads nothing for an asm statement: every consumer of these
+// results sits behind at least four further MFMAs or a barrier plus tens of instructions (16-pass MFMA: 19 wait states).
+__device__ inline void mfma_f8_acc(f32x16_t& d, const i32x8_t& a, const i32x8_t& b, int one) {          // d += a x b
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(a), "v"(b), "v"(one) : "memory");
+}
+__device__ inline void mfma_f8_init(f32x16_t& d, const i32x8_t& a, const i32x8_t& b, const f32x16_t& c, int one) {   // d = a x b + c
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(a), "v"(b), "v"(c), "v"(one) : "memory");
 }
 
 #define F8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -151,15 +180,27 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   const uint32_t k_lane_off = (uint32_t)kr * HD8 + (uint32_t)(((lane & 7) ^ ((kr >> 1) & 7)) << 4);
   const int vr = wave * 16 + (lane >> 2);
   const uint32_t v_lane_off = (uint32_t)vr * (uint32_t)p.sk_pad + (uint32_t)(((lane & 3) ^ ((vr >> 2) & 3)) << 4);
-  const int64_t head_off_k = (int64_t)sh * p.sk_pad * HD8;
-  auto stage = [&](int tt) __attribute__((always_inline)) {
-    const int t = min(tt, total_tiles - 1);              // past the end: re-fetch the last tile into a slot nobody reads
-    const int ch = t / p.tiles_per_chunk, ti = t - ch * p.tiles_per_chunk;
-    const uint8_t* kb = p.K + ch * p.chunk_stride + head_off_k + (int64_t)ti * KT * HD8;
-    const uint8_t* vb = p.Vt + ch * p.chunk_stride + head_off_k + (int64_t)ti * KT;
-    unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_lane_off), (lds_ptr_t)(slot + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + v_lane_off), (lds_ptr_t)(slot + 8192 + wave * 1024), 16, 0, 0);
+  // running source of the next tile to stage (wave-uniform): advances one tile per call, jumps at chunk ends, and stays
+  // on the last tile past the end of the stream (the re-fetch lands in a ring slot nobody reads)
+  const uint8_t* st_k = p.K + (int64_t)sh * p.sk_pad * HD8;
+  const uint8_t* st_v = p.Vt + (int64_t)sh * p.sk_pad * HD8;
+  int st_n = 0, st_ti = 0;
+  auto stage = [&]() __attribute__((always_inline)) {
+    unsigned char* slot = smem + (st_n & (NSTAGE - 1)) * STAGE_BYTES;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(st_k + k_lane_off), (lds_ptr_t)(slot + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(st_v + v_lane_off), (lds_ptr_t)(slot + 8192 + wave * 1024), 16, 0, 0);
+    ++st_n;
+    if (st_n < total_tiles) {
+      if (st_ti == p.tiles_per_chunk - 1) {
+        st_ti = 0;
+        st_k += p.chunk_stride - (int64_t)(p.tiles_per_chunk - 1) * KT * HD8;
+        st_v += p.chunk_stride - (int64_t)(p.tiles_per_chunk - 1) * KT;
+      } else {
+        ++st_ti;
+        st_k += KT * HD8;
+        st_v += KT;
+      }
+    }
   };
 
   // ---- fragment addresses
@@ -188,6 +229,15 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
         kf[kb][s] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
       }
   };
+  auto read_v_half = [&](int tt, int half) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
+#pragma unroll
+    for (int cb = 2 * half; cb < 2 * half + 2; ++cb) {
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[0]);
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[1]);
+      vf[cb] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    }
+  };
   auto read_v = [&](int tt) __attribute__((always_inline)) {
     const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
 #pragma unroll
@@ -203,49 +253,70 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-  auto qk = [&]() __attribute__((always_inline)) {          // S^T = K Q^T for the tile whose fragments are in kf
+  // Scores are born RELATIVE: the QK^T accumulators start from a splat of binit = P_SHIFT - m_run (column q = this lane's
+  // row), so  sc = s - m_run + P_SHIFT  needs no per-element subtraction before the exponential; a re-base (rare) shifts
+  // the scores already in registers.  m_run starts at P_SHIFT (binit = 0) and the first tile always re-bases.
+  float m_run = P_SHIFT, l_run = 0.f;
+  int one = SCALE_ONE;                                       // E8M0 block scales 2^0 (a VGPR operand of the scaled MFMA)
+  asm volatile("" : "+v"(one));
+  float binit = 0.f;                                         // P_SHIFT - m_run: what the score accumulators start from
+  auto sc_init = [&](int kb) __attribute__((always_inline)) {      // 16 moves, issued in the shadow of the P.V MFMAs
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16_t z;
+    for (int r = 0; r < 16; ++r) sc[kb][r] = binit;
+    asm volatile("" : "+v"(sc[kb]));
+  };
+  auto qk = [&]() __attribute__((always_inline)) {          // S^T += K Q^T for the tile whose fragments are in kf
+    asm volatile("s_nop 1" ::: "memory");                   // VALU-written accumulators -> MFMA SrcC
 #pragma unroll
-      for (int r = 0; r < 16; ++r) z[r] = 0.f;
-      z = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[kb][0], qf[0], z, 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
-      sc[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[kb][1], qf[1], z, 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
-    }
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) mfma_f8_acc(sc[kb], kf[kb][s2], qf[s2], one);
   };
 
-  float m_run = -INFINITY, l_run = 0.f;
-  i32x8_t pf;                                                // P^T B operand: byte j = 16 kb + r
+  i32x8_t pf = {0, 0, 0, 0, 0, 0, 0, 0};                     // P^T B operand: byte j = 16 kb + r
   const int tail_valid = p.sk - (p.tiles_per_chunk - 1) * KT;   // valid keys in a chunk's last tile (1 .. 64)
+  int tic = 0;                                               // tile-in-chunk counter of the softmax tile
 
-  auto softmax = [&](int tt) __attribute__((always_inline)) {
-    const bool masked = tail_valid < KT && (tt % p.tiles_per_chunk) == p.tiles_per_chunk - 1;
-    if (masked) {
+  auto softmax = [&](bool first) __attribute__((always_inline)) {
+    const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
+    tic = last_of_chunk ? 0 : tic + 1;
+    if (last_of_chunk && tail_valid < KT) {                  // wave-uniform, once per chunk: keys past the chunk's end
+      asm volatile("" ::: "memory");                         // (keeps this a branch: if-converted it costs 32 selects per tile)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi >= tail_valid) sc[kb][r] = -INFINITY;
     }
-    float mx = fmaxf(sc[0][0], sc[1][0]);
+    // row max: four independent chains (v_max3 under -fno-honor-nans), then the other half of the row
+    float mxa[4];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[0][r], sc[1][r]));
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
-    if (__builtin_amdgcn_ballot_w64(mx > m_run + DEFER_T) != 0) {       // rare after the first tiles: move the base
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+    for (int i = 0; i < 4; ++i) mxa[i] = fmaxf(fmaxf(sc[0][i], sc[1][i]), sc[0][i + 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = fmaxf(fmaxf(mxa[i], sc[1][i + 4]), sc[0][i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = fmaxf(fmaxf(mxa[i], sc[1][i + 8]), sc[0][i + 12]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mxa[i] = fmaxf(mxa[i], sc[1][i + 12]);
+    float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
+    mx = fmaxf(mx, other_half(mx, hi));
+    // relative to the running max the row max is mx - P_SHIFT; re-base when it is above 2^DEFER_T (or on the first tile)
+    if (first || __builtin_amdgcn_ballot_w64(mx > P_SHIFT + DEFER_T) != 0) {
+      const float delta = first ? mx - P_SHIFT : fmaxf(mx - P_SHIFT, 0.f);
+      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
       l_run *= alpha;
-      m_run = m_new;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+      m_run += delta;
+      binit = P_SHIFT - m_run;
     }
-    const float base = P_SHIFT - m_run;
-    float ps = 0.f;
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};                      // four independent row-sum chains (fp32, before the rounding)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -253,42 +324,55 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
         float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(sc[kb][4 * q4 + i] + base);
-          ps += e[i];
+          e[i] = __builtin_amdgcn_exp2f(sc[kb][4 * q4 + i]);
+          ps[i] += e[i];
         }
-        int w = 0;
+        int w = pf[4 * kb + q4];                               // both halves are overwritten: no zero-initialising move
         w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w, false);
         w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
         pf[4 * kb + q4] = w;
       }
-    l_run += ps;
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
   };
 
-  // ---- prologue: tiles 0 .. 2 in flight, S(0) computed by both groups, then group 1 drops half a tile behind ------
-  stage(0); stage(1); stage(2);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // ---- schedule.  Per tile t a wave runs a softmax interval V(t) - VALU only - and a matrix interval M(t):
+  //   V(t):  softmax of S(t) -> P(t)                                  | s_waitcnt vmcnt(2) (tile t+3 landed), lgkmcnt(0), barrier
+  //   M(t):  O += V^T(t) P(t), S(t+1) = K(t+1) Q^T; between the MFMAs (the wave only waits for the matrix pipe
+  //          there, so the issue slots are free): fragment reads of K(t+2) and V(t+1) into the registers the MFMAs have
+  //          just consumed, and the LDS-DMA of tile t+5                | barrier
+  // Group 1 runs one interval behind group 0, so on every SIMD one wave multiplies while the other exponentiates.
+  // A tile is read by the other group up to one interval after this wave's wait for it: tile t+3 is retired at the end of
+  // V(t) and first read in M(t+1).
+  stage(); stage(); stage(); stage(); stage();            // tiles 0 .. 4
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   F8_BARRIER();
   read_k(0);
-  qk();
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  sc_init(0); sc_init(1);
+  qk();                                                   // S(0) (every lane's m_run is still P_SHIFT: the accumulators start from 0)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // asm MFMA results: nothing is padded for the first softmax
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tiles 1, 2
   F8_BARRIER();
+  read_k(1);
+  read_v(0);
   if (grp == 1) F8_BARRIER();
 
   for (int t = 0; t < total_tiles; ++t) {
-    // softmax interval: fetch the operands of the matrix interval behind it, issue the DMA of tile t + 3, then the VALU work
-    read_v(t);
-    read_k(t + 1);                       // t + 1 == total_tiles: a landed, unused slot (the clamped re-fetch of the last tile)
-    stage(t + 3);
-    softmax(t);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // this wave's pieces of tile t + 2 have landed
+    softmax(t == 0);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     F8_BARRIER();
-    // matrix interval
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-      o[cb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[cb], pf, o[cb], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
-    qk();
+    mfma_f8_acc(o[0], vf[0], pf, one);                     // O += V^T(t) P(t)
+    mfma_f8_acc(o[1], vf[1], pf, one);
+    sc_init(0);
+    read_v_half(t + 1, 0);
+    mfma_f8_acc(o[2], vf[2], pf, one);
+    mfma_f8_acc(o[3], vf[3], pf, one);
+    sc_init(1);
+    read_v_half(t + 1, 1);
+    stage();                                               // tile t + 5
+    qk();                                                  // S(t+1): consumes kf = K(t+1)
+    read_k(t + 2);
     __builtin_amdgcn_s_setprio(0);
     F8_BARRIER();
   }
@@ -296,10 +380,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- normalise and store: lane (row l31, half hi) holds channels 32 cb + 8 g + 4 hi .. + 3 in registers 4 g .. 4 g + 3
-  {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run), __builtin_bit_cast(unsigned, l_run), false, false);
-    l_run = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-  }
+  l_run += other_half(l_run, hi);
   if (qrow < p.sq) {
     const float inv = 1.f / l_run;
     bf16_t* op = p.O + ((int64_t)seq * p.sq + qrow) * p.ldo + head * HD8;

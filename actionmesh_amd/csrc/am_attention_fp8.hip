@@ -147,6 +147,9 @@ struct f8_args {
   int64_t chunk_stride;
 };
 
+// ABL: timing ablations (numerically meaningless; tools/kernel_bench.py --ablate-fp8): 1 no exponentials, 2 no LDS-DMA in the
+// loop, 4 no fragment reads in the loop, 8 no MFMAs in the loop, 16 no row max.
+template <int ABL>
 __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -229,14 +232,17 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
         kf[kb][s] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
       }
   };
-  auto read_v_half = [&](int tt, int half) __attribute__((always_inline)) {
+  auto read_v1 = [&](int tt, int cb) __attribute__((always_inline)) {          // one V^T fragment (2 ds_read_b128)
     const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
-#pragma unroll
-    for (int cb = 2 * half; cb < 2 * half + 2; ++cb) {
-      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[0]);
-      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[1]);
-      vf[cb] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-    }
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + cb * 32 * 64 + v_off[1]);
+    vf[cb] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  auto read_k1 = [&](int tt, int kb, int s2) __attribute__((always_inline)) {   // one K fragment (2 ds_read_b128)
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + kb * 32 * HD8 + k_off[s2][0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + kb * 32 * HD8 + k_off[s2][1]);
+    kf[kb][s2] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
   auto read_v = [&](int tt) __attribute__((always_inline)) {
     const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) mxa[i] = fmaxf(mxa[i], sc[1][i + 12]);
     float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
+    if (ABL & 16) mx = sc[0][0];
     mx = fmaxf(mx, other_half(mx, hi));
     // relative to the running max the row max is mx - P_SHIFT; re-base when it is above 2^DEFER_T (or on the first tile)
     if (first || __builtin_amdgcn_ballot_w64(mx > P_SHIFT + DEFER_T) != 0) {
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
         float e[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          e[i] = __builtin_amdgcn_exp2f(sc[kb][4 * q4 + i]);
+          e[i] = (ABL & 1) ? sc[kb][4 * q4 + i] : __builtin_amdgcn_exp2f(sc[kb][4 * q4 + i]);
           ps[i] += e[i];
         }
         int w = pf[4 * kb + q4];                               // both halves are overwritten: no zero-initialising move
@@ -336,10 +343,10 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   };
 
   // ---- schedule.  Per tile t a wave runs a softmax interval V(t) - VALU only - and a matrix interval M(t):
-  //   V(t):  softmax of S(t) -> P(t)                                  | s_waitcnt vmcnt(2) (tile t+3 landed), lgkmcnt(0), barrier
-  //   M(t):  O += V^T(t) P(t), S(t+1) = K(t+1) Q^T; between the MFMAs (the wave only waits for the matrix pipe
-  //          there, so the issue slots are free): fragment reads of K(t+2) and V(t+1) into the registers the MFMAs have
-  //          just consumed, and the LDS-DMA of tile t+5                | barrier
+  //   V(t):  LDS-DMA of tile t+5; softmax of S(t) -> P(t)              | s_waitcnt vmcnt(4) (tile t+3 landed), lgkmcnt(0), barrier
+  //   M(t):  O += V^T(t) P(t), S(t+1) = K(t+1) Q^T; in the gaps between the MFMAs (one MFMA time of free issue each): the
+  //          fragment reads of V(t+1) and K(t+2) into the registers the MFMAs have just consumed, and the moves that
+  //          initialise the score accumulators                        | barrier
   // Group 1 runs one interval behind group 0, so on every SIMD one wave multiplies while the other exponentiates.
   // A tile is read by the other group up to one interval after this wave's wait for it: tile t+3 is retired at the end of
   // V(t) and first read in M(t+1).
@@ -357,24 +364,37 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   if (grp == 1) F8_BARRIER();
 
   for (int t = 0; t < total_tiles; ++t) {
+    if (!(ABL & 2)) stage();                               // tile t + 5
     softmax(t == 0);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile t + 3 (tiles t + 4, t + 5 stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ABL & 64) __builtin_amdgcn_s_setprio(0);
     F8_BARRIER();
-    __builtin_amdgcn_s_setprio(1);
-    mfma_f8_acc(o[0], vf[0], pf, one);                     // O += V^T(t) P(t)
-    mfma_f8_acc(o[1], vf[1], pf, one);
+    if (!(ABL & 96)) __builtin_amdgcn_s_setprio(1);
+    // Between two MFMAs the wave has one MFMA time (64 cycles) of free issue: the fragment reads (into registers whose MFMA
+    // has been issued) and the accumulator-initialising moves are spread over the gaps, two reads / eight moves at most each.
+    constexpr bool MM = !(ABL & 8), RD = !(ABL & 4);
+    if (MM) mfma_f8_acc(o[0], vf[0], pf, one);             // O += V^T(t) P(t)
+    if (MM) mfma_f8_acc(o[1], vf[1], pf, one);
+    if (RD) read_v1(t + 1, 0);
     sc_init(0);
-    read_v_half(t + 1, 0);
-    mfma_f8_acc(o[2], vf[2], pf, one);
-    mfma_f8_acc(o[3], vf[3], pf, one);
+    if (MM) mfma_f8_acc(o[2], vf[2], pf, one);
+    if (RD) read_v1(t + 1, 1);
+    if (MM) mfma_f8_acc(o[3], vf[3], pf, one);
+    if (RD) read_v1(t + 1, 2);
     sc_init(1);
-    read_v_half(t + 1, 1);
-    stage();                                               // tile t + 5
-    qk();                                                  // S(t+1): consumes kf = K(t+1)
-    read_k(t + 2);
-    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_nop 1" ::: "memory");                  // VALU-written accumulators -> MFMA SrcC
+    if (MM) mfma_f8_acc(sc[0], kf[0][0], qf[0], one);      // S(t+1) = K(t+1) Q^T
+    if (RD) read_v1(t + 1, 3);
+    if (MM) mfma_f8_acc(sc[1], kf[1][0], qf[0], one);
+    if (RD) read_k1(t + 2, 0, 0);
+    if (MM) mfma_f8_acc(sc[0], kf[0][1], qf[1], one);
+    if (RD) read_k1(t + 2, 1, 0);
+    if (MM) mfma_f8_acc(sc[1], kf[1][1], qf[1], one);
+    if (RD) { read_k1(t + 2, 0, 1); read_k1(t + 2, 1, 1); }
+    if (!(ABL & 96)) __builtin_amdgcn_s_setprio(0);
     F8_BARRIER();
+    if (ABL & 64) __builtin_amdgcn_s_setprio(1);           // priority to the softmax interval instead
   }
   if (grp == 0) F8_BARRIER();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -441,8 +461,9 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   AM_HIP(hipGetDevice(&dev));
   AM_CHECK(dev >= 0 && dev < 64, "am_attention_fp8: device index %d", dev);
   if (!attr_set[dev]) {
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               NSTAGE * STAGE_BYTES));
+#define F8_ATTR(A) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
+    F8_ATTR(0); F8_ATTR(1); F8_ATTR(2); F8_ATTR(4); F8_ATTR(8); F8_ATTR(16); F8_ATTR(17); F8_ATTR(6); F8_ATTR(32); F8_ATTR(64); F8_ATTR(40);
+#undef F8_ATTR
     attr_set[dev] = true;
   }
   f8_args p;
@@ -450,8 +471,23 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;
   p.nchunks = a->nchunks; p.tiles_per_chunk = (a->sk + KT - 1) / KT; p.ldo = a->ldo;
   p.chunk_stride = a->nchunks > 1 ? a->chunk_stride : 0;
-  hipLaunchKernelGGL(attn_fp8_kernel, dim3(a->sq_pad / 256, a->nseq * a->heads), dim3(512), NSTAGE * STAGE_BYTES,
-                     (hipStream_t)stream, p);
+  const dim3 grid(a->sq_pad / 256, a->nseq * a->heads);
+#define F8_LAUNCH(A) hipLaunchKernelGGL(attn_fp8_kernel<A>, grid, dim3(512), NSTAGE * STAGE_BYTES, (hipStream_t)stream, p)
+  switch (a->defer_log2 >= 5000 ? a->defer_log2 - 5000 : 0) {     // 5000 + ABL: timing ablations
+    case 0: F8_LAUNCH(0); break;
+    case 1: F8_LAUNCH(1); break;
+    case 2: F8_LAUNCH(2); break;
+    case 4: F8_LAUNCH(4); break;
+    case 6: F8_LAUNCH(6); break;
+    case 8: F8_LAUNCH(8); break;
+    case 16: F8_LAUNCH(16); break;
+    case 17: F8_LAUNCH(17); break;
+    case 32: F8_LAUNCH(32); break;
+    case 64: F8_LAUNCH(64); break;
+    case 40: F8_LAUNCH(40); break;
+    default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
+  }
+#undef F8_LAUNCH
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

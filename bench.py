@@ -117,7 +117,7 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
     peak = PEAK_FP8_TFLOPS if dtype == "fp8" else PEAK_BF16_TFLOPS
 
     def sample(qscale):
-        Q = (Qf * qscale).to(torch.bfloat16)
+        Q = (Qf * qscale).to(torch.bfloat16)          # fp8: one launch = quantise pass + attention kernel, as the model runs a layer
         attn(Q, K, Vt, Sq, Sq, out=out, nchunks=fw)
         torch.cuda.synchronize()
         f0 = ops.attention_fallback_count()
@@ -236,6 +236,10 @@ def main():
     ap.add_argument("--shape", default="headline", choices=list(SHAPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the inflated self-attention (QK^T, P.V) on the e4m3 MX-scaled MFMA kernel - BASELINE.json "
+                         "configs[4] (use with --shape long64); GEMMs, norms and the residual stream stay bf16.  The headline "
+                         "metric is bf16.")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -259,7 +263,7 @@ def main():
     hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0,
               cross_attention_dim=Dc, inflated_layers=list(range(NL)))
     sd = random_state_dict(hp, seed=0)
-    model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, **hp)
+    model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, attn_dtype=args.dtype, **hp)
     model.load_state_dict(sd)
     model.to(dev).eval()
 
@@ -300,15 +304,17 @@ def main():
         "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
         "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
                                f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
-                               "random-init weights, seeded N(0,1) latents/context resident in HBM",
+                               "random-init weights, seeded N(0,1) latents/context resident in HBM"
+                               + ("; self-attention in fp8 e4m3 (everything else bf16)" if args.dtype == "fp8" else ""),
                    "parallelism": ("single GPU" if world == 1 else
                                    f"cfg-branch x{2 if world % 2 == 0 else 1} * frame-shard x{world // (2 if world % 2 == 0 else 1)}"),
                    "step_flops": step_flops},
         "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
         "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if args.dtype == "fp8" else PEAK_BF16_TFLOPS), 4),
         # second half of BASELINE.json's metric: needs the pretrained checkpoints (facebook/ActionMesh, TripoSG, RMBG) and a
         # real video, none reachable offline - not measured here, and nothing in `value` stands in for it
         "end_to_end_video_to_4d_s": None,
@@ -316,7 +322,7 @@ def main():
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
     }
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = attention_roofline(T, N, H, dev, world)
+        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=args.dtype)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del model
         torch.cuda.empty_cache()

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
     ap.add_argument("--ablate64", action="store_true", help="time the 4x64 kernel's ablations (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
+    ap.add_argument("--ablate-fp8", action="store_true", help="attn: time the fp8 kernel's ablations")
     ap.add_argument("--ablate-gemm", action="store_true", help="gemm: time the epilogue ablations (no C stores / no residual loads)")
     ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
     ap.add_argument("--blas", action="store_true", help="gemm: also time torch.matmul (hipBLASLt) on the same operands - the "
@@ -62,6 +63,11 @@ def main():
             qz = ops.attention_fp8.last_quantized
             ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (attend only)        : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if a.ablate_fp8:
+            qz = ops.attention_fp8.last_quantized
+            for k, nm in {1: "no exp", 16: "no row max", 17: "no exp, no row max", 2: "no LDS-DMA", 4: "no fragment reads", 6: "no DMA, no reads", 8: "no MFMAs", 32: "no s_setprio (full kernel)", 64: "s_setprio 1 on the softmax interval (full)", 40: "no setprio, no MFMAs"}.items():
+                ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
+                print(f"  fp8 ablation {nm:24s}: {ms:8.3f} ms")
         if a.ablate64:
             for k, nm in {1: "no exp", 2: "no row max", 4: "no barrier / DMA drain", 8: "no exp/sum/pack", 10: "no softmax VALU",
                           14: "no softmax VALU, no barrier", 16: "no LDS fragment addressing (same stage)", 30: "MFMA + fragment reads only", 32: "no exp/sum/pack beside P.V (phase 1b)", 64: "no exp/sum/pack beside QK^T (phase 2b)", 128: "no LDS fragment reads", 132: "no LDS reads, no barrier",

@@ -1,0 +1,46 @@
+"""Real multi-rank runs (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI).  Auto-skip on boxes with
+fewer than two devices (the build pool hands out single-GPU boxes; a multi-GPU driver box exercises these): RCCL ranks,
+the CFG-branch x frame-shard groups, the asynchronous [K | V^T] all-gather overlapped with the local-shard attention, and
+1-vs-N parity of the sharded forward (tools/mgpu_selftest.py: rel-L2 < 1e-2 vs the unsharded forward on rank 0)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "mgpu_selftest.py"), *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "[mgpu_selftest] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_forward_on_real_ranks(world):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, found {torch.cuda.device_count() if torch.cuda.is_available() else 0}")
+    out = _run(world)
+    print(out.strip().splitlines()[-2])
+
+
+def test_short_window_falls_back_to_replicas():
+    """7 frames over 2 frame shards per CFG branch do not divide: every rank of a branch computes all frames."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 4:
+        pytest.skip("needs 4 GPUs")
+    _run(4, ("--frames", "7"))

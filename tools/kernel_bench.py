@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time the AM_ATTN_ABLATIONS variants (needs that build)")
     ap.add_argument("--ablate64", action="store_true", help="time the 4x64 kernel's ablations (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
+    ap.add_argument("--fp8", action="store_true", help="attn: the fp8 kernel too when --product-only")
     ap.add_argument("--ablate-fp8", action="store_true", help="attn: time the fp8 kernel's ablations")
     ap.add_argument("--ablate-gemm", action="store_true", help="gemm: time the epilogue ablations (no C stores / no residual loads)")
     ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
@@ -57,7 +58,7 @@ def main():
                 continue
             ms = timeit(lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=d), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} variant={d:3d} ({nm:12s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
-        if not a.product_only:
+        if not a.product_only or a.fp8:
             ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (quantise + attend)  : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
             qz = ops.attention_fp8.last_quantized
@@ -108,6 +109,8 @@ def main():
             bias = torch.randn(Nn, device=dev) if kw.get("bias") else None
             res = rnd(R, Nn) if kw.get("res") else None
             for small, leg, nm in ((False, False, "256sq-pingpong"), (False, True, "256sq-lockstep"), (True, False, "128sq-regstage")):
+                if a.product_only and (small or leg):
+                    continue
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
                                              force_small=small, legacy=leg), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")

@@ -265,18 +265,15 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   float m_run = P_SHIFT, l_run = 0.f;
   int one = SCALE_ONE;                                       // E8M0 block scales 2^0 (a VGPR operand of the scaled MFMA)
   asm volatile("" : "+v"(one));
-  float binit = 0.f;                                         // P_SHIFT - m_run: what the score accumulators start from
-  auto sc_init = [&](int kb) __attribute__((always_inline)) {      // 16 moves, issued in the shadow of the P.V MFMAs
+  f32x16_t bsplat;                                           // P_SHIFT - m_run in 16 registers: SrcC of the first QK^T MFMAs,
+#pragma unroll                                               // rewritten on a re-base only
+  for (int r = 0; r < 16; ++r) bsplat[r] = 0.f;
+  asm volatile("" : "+v"(bsplat));
+  auto qk = [&]() __attribute__((always_inline)) {          // S^T = K Q^T + splat for the tile whose fragments are in kf
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[kb][r] = binit;
-    asm volatile("" : "+v"(sc[kb]));
-  };
-  auto qk = [&]() __attribute__((always_inline)) {          // S^T += K Q^T for the tile whose fragments are in kf
-    asm volatile("s_nop 1" ::: "memory");                   // VALU-written accumulators -> MFMA SrcC
+    for (int kb = 0; kb < 2; ++kb) mfma_f8_init(sc[kb], kf[kb][0], qf[0], bsplat, one);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) mfma_f8_acc(sc[kb], kf[kb][s2], qf[s2], one);
+    for (int kb = 0; kb < 2; ++kb) mfma_f8_acc(sc[kb], kf[kb][1], qf[1], one);
   };
 
   i32x8_t pf = {0, 0, 0, 0, 0, 0, 0, 0};                     // P^T B operand: byte j = 16 kb + r
@@ -321,7 +318,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
       m_run += delta;
-      binit = P_SHIFT - m_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsplat[r] = P_SHIFT - m_run;
     }
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                      // four independent row-sum chains (fp32, before the rounding)
 #pragma unroll
@@ -345,8 +343,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   // ---- schedule.  Per tile t a wave runs a softmax interval V(t) - VALU only - and a matrix interval M(t):
   //   V(t):  LDS-DMA of tile t+5; softmax of S(t) -> P(t)              | s_waitcnt vmcnt(4) (tile t+3 landed), lgkmcnt(0), barrier
   //   M(t):  O += V^T(t) P(t), S(t+1) = K(t+1) Q^T; in the gaps between the MFMAs (one MFMA time of free issue each): the
-  //          fragment reads of V(t+1) and K(t+2) into the registers the MFMAs have just consumed, and the moves that
-  //          initialise the score accumulators                        | barrier
+  //          fragment reads of V(t+1) and K(t+2) into the registers the MFMAs have just consumed               | barrier
   // Group 1 runs one interval behind group 0, so on every SIMD one wave multiplies while the other exponentiates.
   // A tile is read by the other group up to one interval after this wave's wait for it: tile t+3 is retired at the end of
   // V(t) and first read in M(t+1).
@@ -354,7 +351,6 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   F8_BARRIER();
   read_k(0);
-  sc_init(0); sc_init(1);
   qk();                                                   // S(0) (every lane's m_run is still P_SHIFT: the accumulators start from 0)
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // asm MFMA results: nothing is padded for the first softmax
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tiles 1, 2
@@ -377,16 +373,13 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
     if (MM) mfma_f8_acc(o[0], vf[0], pf, one);             // O += V^T(t) P(t)
     if (MM) mfma_f8_acc(o[1], vf[1], pf, one);
     if (RD) read_v1(t + 1, 0);
-    sc_init(0);
     if (MM) mfma_f8_acc(o[2], vf[2], pf, one);
     if (RD) read_v1(t + 1, 1);
     if (MM) mfma_f8_acc(o[3], vf[3], pf, one);
     if (RD) read_v1(t + 1, 2);
-    sc_init(1);
-    asm volatile("s_nop 1" ::: "memory");                  // VALU-written accumulators -> MFMA SrcC
-    if (MM) mfma_f8_acc(sc[0], kf[0][0], qf[0], one);      // S(t+1) = K(t+1) Q^T
+    if (MM) mfma_f8_init(sc[0], kf[0][0], qf[0], bsplat, one);      // S(t+1) = K(t+1) Q^T + (P_SHIFT - m_run)
     if (RD) read_v1(t + 1, 3);
-    if (MM) mfma_f8_acc(sc[1], kf[1][0], qf[0], one);
+    if (MM) mfma_f8_init(sc[1], kf[1][0], qf[0], bsplat, one);
     if (RD) read_k1(t + 2, 0, 0);
     if (MM) mfma_f8_acc(sc[0], kf[0][1], qf[1], one);
     if (RD) read_k1(t + 2, 1, 0);

@@ -119,9 +119,24 @@ def main():
                     ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out, ablate=ab), a.reps)
                     print(f"  gemm {name:13s} ablation {nm:18s}: {ms:8.3f} ms")
             if a.blas:
+                import torch.nn.functional as F
                 Wt = W.t()
                 ms = timeit(lambda: torch.matmul(A, Wt, out=out), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} hipBLASLt(plain): {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+                # the op sequence the reference runs for this linear under autocast (vendor GEMM + separate elementwise passes):
+                # F.linear(+bias), F.gelu, the residual add of block.py:137-152, the torch.cat of block.py:131
+                bb = bias.to(torch.bfloat16) if bias is not None else None
+                if name.startswith("skip"):
+                    h1, h2 = A[:, :Kk // 2].contiguous(), A[:, Kk // 2:].contiguous()
+                    fn = lambda: F.linear(torch.cat([h1, h2], dim=-1), W, bb)
+                elif kw.get("gelu"):
+                    fn = lambda: F.gelu(F.linear(A, W, bb))
+                elif kw.get("res"):
+                    fn = lambda: res + F.linear(A, W, bb)
+                else:
+                    fn = lambda: F.linear(A, W, bb)
+                ms = timeit(fn, a.reps)
+                print(f"gemm {name:13s} M={R} N={Nn} K={Kk} torch op sequence (library GEMM + elementwise): {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             del A, W, out, res
     if "ln" in only:
         x = rnd(R, C); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)

@@ -98,6 +98,14 @@ SYMBOLS = {
     "am_attention_bf16": (C.c_int, [C.POINTER(AmAttnArgs), _P]),
     "am_attention_quantize_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
     "am_attention_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
+    "am_peer_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "am_peer_free": (C.c_int, [_P]),
+    "am_peer_export": (C.c_int, [_P, _P]),
+    "am_peer_open": (C.c_int, [_P, C.POINTER(_P)]),
+    "am_peer_close": (C.c_int, [_P]),
+    "am_peer_copy": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "am_peer_signal": (C.c_int, [_P, C.c_uint32, _P]),
+    "am_peer_wait": (C.c_int, [_P, C.c_uint32, _P, _P]),
     "am_f32_to_bf16": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

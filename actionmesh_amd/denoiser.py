@@ -78,7 +78,8 @@ class HipEngine:
 
     def __init__(self, hp: Dict, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  max_batch: int, frames_local: int, tokens: int, ctx_tokens: int,
-                 world: int = 1, rank: int = 0, attn_defer_log2: int = 8, attn_dtype: str = "bf16"):
+                 world: int = 1, rank: int = 0, attn_defer_log2: int = 8, attn_dtype: str = "bf16",
+                 kv_factory=None):
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -113,20 +114,29 @@ class HipEngine:
             if missing:
                 raise RuntimeError(f"HipEngine: {missing} reference state-dict keys were not provided")
             self._kv = None
+            self.exchange = None
             if world > 1:
                 n = C.c_size_t()
                 L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
                 # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands
-                kv = torch.zeros((world, 2 * n.value), dtype=torch.bfloat16, device=self.device)
-                L.check(self.lib.am_bind_kv_buffers(self.handle, kv.data_ptr(), kv.data_ptr() + n.value * kv.element_size(),
-                                                    2 * n.value), "am_bind_kv_buffers")
-                self._kv = (kv,)
+                if kv_factory is not None:      # copy-engine back-end: the buffer is an IPC-shared hipMalloc, not a torch tensor
+                    self.exchange = kv_factory(2 * n.value * 2)
+                    base = self.exchange.kv_ptr()
+                else:
+                    kv = torch.zeros((world, 2 * n.value), dtype=torch.bfloat16, device=self.device)
+                    base = kv.data_ptr()
+                    self._kv = (kv,)
+                L.check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
         self._shape = None
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.am_destroy(self.handle)
             self.handle = None
+        ex = getattr(self, "exchange", None)
+        if ex is not None:
+            self.exchange = None
+            ex.close()
 
     def __del__(self):
         try:
@@ -305,9 +315,14 @@ class HipDenoiser(nn.Module):
             return e
         if e is not None:
             e.close()
+        kv_factory = None
+        if plan.frame_world > 1 and os.environ.get("ACTIONMESH_AMD_EXCHANGE", "rccl") == "peer":
+            from .sharding import PeerExchange
+            group = self._frame_group(plan)
+            kv_factory = lambda chunk_bytes: PeerExchange(group, plan, chunk_bytes, self.device)
         self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
                                  world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2,
-                                 attn_dtype=self.attn_dtype)
+                                 attn_dtype=self.attn_dtype, kv_factory=kv_factory)
         self._window = None
         return self._engine
 
@@ -350,7 +365,7 @@ class HipDenoiser(nn.Module):
         if plan.frame_world == 1:                       # pure CFG split: no K/V exchange at all
             v_local = e.forward(x_local, t_local)
         else:
-            v_local = sharded_forward(e, plan, self._frame_group(plan), x_local, t_local)
+            v_local = sharded_forward(e, plan, self._frame_group(plan), x_local, t_local, exchange=getattr(e, "exchange", None))
         return gather_frames(v_local, plan, self.process_group)
 
     def forward(self, hidden_states: torch.Tensor, context: torch.Tensor, framestep: torch.Tensor,

@@ -17,6 +17,7 @@ The driver below is engine-agnostic: the product engine is `HipEngine`
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Protocol, Tuple
 
@@ -133,8 +134,117 @@ def exchange_kv(kv: Tuple[torch.Tensor, ...], plan: FrameShardPlan, group: Optio
     return works
 
 
+class PeerExchange:
+    """The per-layer [K | V^T] all-gather of one frame group as P-1 pushes on the COPY ENGINES (no RCCL kernels, no CUs
+    beside two one-lane flag kernels): the alternative exchange back-end, selected with ACTIONMESH_AMD_EXCHANGE=peer.
+
+    Every rank owns one gather buffer [frame_world][chunk] and one flag block, both hipMalloc'd by the library and shared with
+    the other ranks of the group through HIP IPC handles (exchanged once over the process group's control plane).  Per
+    exchange `seq`:
+      start():  side stream waits for the compute stream (this rank's shard is written), then for every peer p, in ring
+                order: wait until p has CONSUMED this rank's previous shard (p's flag consumed[me] >= seq - 1 in MY block:
+                the slot in p's buffer may be overwritten), SDMA-copy the shard into p's buffer slot `me`, raise
+                arrived[me] = seq in p's block;
+      wait():   the compute stream waits for arrived[p] >= seq of every peer p (the remote shards are in MY buffer);
+      done():   after the attention that reads them has been enqueued, raise consumed[me] = seq in every peer's block.
+    Flags live in the OWNER's memory and are written remotely, so every wait polls local memory."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup], plan: FrameShardPlan, chunk_bytes: int, device: torch.device):
+        import ctypes as C
+        from . import _lib as L
+        self.L, self.C = L, C
+        self.lib = L.lib()
+        self.plan, self.device = plan, torch.device(device)
+        self.P, self.me = plan.frame_world, plan.frame_rank
+        self.chunk_bytes = int(chunk_bytes)
+        self.seq = 0
+        with torch.cuda.device(self.device):
+            self.kv = C.c_void_p()
+            L.check(self.lib.am_peer_alloc(self.P * self.chunk_bytes, C.byref(self.kv)), "am_peer_alloc")
+            self.flags = C.c_void_p()                       # uint32: arrived[P] | consumed[P] | fault
+            L.check(self.lib.am_peer_alloc(4 * (2 * self.P + 1), C.byref(self.flags)), "am_peer_alloc")
+            hk, hf = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+            L.check(self.lib.am_peer_export(self.kv, hk), "am_peer_export")
+            L.check(self.lib.am_peer_export(self.flags, hf), "am_peer_export")
+            mine = (bytes(hk), bytes(hf), os.getpid())
+            allh = [None] * dist.get_world_size(group)
+            dist.all_gather_object(allh, mine, group=group)
+            self.peer_kv, self.peer_flags = {}, {}
+            for p in range(self.P):
+                if p == self.me:
+                    continue
+                kb, fb, _pid = allh[p]
+                pk, pf = C.c_void_p(), C.c_void_p()
+                L.check(self.lib.am_peer_open((C.c_uint8 * 64).from_buffer_copy(kb), C.byref(pk)), "am_peer_open")
+                L.check(self.lib.am_peer_open((C.c_uint8 * 64).from_buffer_copy(fb), C.byref(pf)), "am_peer_open")
+                self.peer_kv[p], self.peer_flags[p] = pk.value, pf.value
+            self.side = torch.cuda.Stream(self.device)
+        self._group = group
+
+    def kv_ptr(self) -> int:
+        return self.kv.value
+
+    def _arrived(self, base: int, src: int) -> int:
+        return base + 4 * src
+
+    def _consumed(self, base: int, reader: int) -> int:
+        return base + 4 * (self.P + reader)
+
+    def start(self) -> None:
+        self.seq += 1
+        comp = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(comp)
+        self.side.wait_event(ev)
+        st = self.side.cuda_stream
+        fault = self.flags.value + 4 * 2 * self.P
+        with torch.cuda.device(self.device):
+            for i in range(1, self.P):
+                p = (self.me + i) % self.P
+                if self.seq > 1:
+                    self.L.check(self.lib.am_peer_wait(self._consumed(self.flags.value, p), self.seq - 1, fault, st), "am_peer_wait")
+                off = self.me * self.chunk_bytes
+                self.L.check(self.lib.am_peer_copy(self.peer_kv[p] + off, self.kv.value + off, self.chunk_bytes, st), "am_peer_copy")
+                self.L.check(self.lib.am_peer_signal(self._arrived(self.peer_flags[p], self.me), self.seq, st), "am_peer_signal")
+
+    def wait(self) -> None:
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        fault = self.flags.value + 4 * 2 * self.P
+        with torch.cuda.device(self.device):
+            for p in range(self.P):
+                if p != self.me:
+                    self.L.check(self.lib.am_peer_wait(self._arrived(self.flags.value, p), self.seq, fault, st), "am_peer_wait")
+
+    def done(self) -> None:
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            for p in range(self.P):
+                if p != self.me:
+                    self.L.check(self.lib.am_peer_signal(self._consumed(self.peer_flags[p], self.me), self.seq, st), "am_peer_signal")
+
+    def faulted(self) -> bool:
+        """True when a flag wait gave up (a peer died or fell > 20 s behind).  Synchronises the device."""
+        t = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.L.check(self.lib.am_peer_copy(t.data_ptr(), self.flags.value + 4 * 2 * self.P, 4,
+                                               torch.cuda.current_stream(self.device).cuda_stream), "am_peer_copy")
+        return bool(t.item())
+
+    def close(self) -> None:
+        if getattr(self, "kv", None) is None:
+            return
+        torch.cuda.synchronize(self.device)
+        if self._group is not None:
+            dist.barrier(group=self._group)          # nobody unmaps a buffer a peer may still push into
+        for ptr in list(self.peer_kv.values()) + list(self.peer_flags.values()):
+            self.lib.am_peer_close(ptr)
+        self.lib.am_peer_free(self.kv)
+        self.lib.am_peer_free(self.flags)
+        self.kv = None
+
+
 def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
-                    x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
+                    x_local: torch.Tensor, t_bt_local: List[float], exchange: Optional[PeerExchange] = None) -> torch.Tensor:
     """One denoiser forward over this rank's (batch rows, frames); returns the local velocity.
     `group` = the frame group of this rank (ranks that share its CFG branch).
     Engines that offer `layer_attn_local` (HipEngine) overlap the exchange with the attention of the full query
@@ -144,6 +254,14 @@ def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.P
     attn_local = getattr(engine, "layer_attn_local", None)
     for i in range(engine.num_layers):
         engine.layer_pre(i)
+        if plan.frame_world > 1 and engine.is_inflated(i) and exchange is not None:
+            exchange.start()                  # copy engines: the pushes run beside the local-shard attention
+            if attn_local is not None:
+                attn_local(i)
+            exchange.wait()
+            engine.layer_post(i)
+            exchange.done()
+            continue
         if plan.frame_world > 1 and engine.is_inflated(i):
             if attn_local is not None:
                 works = exchange_kv(engine.kv_buffers(), plan, group, async_op=True)

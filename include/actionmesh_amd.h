@@ -224,6 +224,23 @@ int am_attention_fallback_count(uint64_t* count);
 int am_attention_quantize_fp8(const am_attn_args* args, uint8_t* q8, uint8_t* k8, uint8_t* vt8, void* stream);
 int am_attention_fp8(const am_attn_args* args, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8, void* stream);
 
+/* Copy-engine exchange of the K / V^T shards between ranks (multi-GPU, one process per GPU; the alternative to the RCCL
+ * all-gather of seam S2's phase API, sharding.py PeerExchange): IPC-shareable device buffers, SDMA copies between them, and
+ * sequence flags written / awaited in stream order by one-lane kernels.
+ *   am_peer_alloc / free      hipMalloc'd (zeroed) buffer whose IPC handle can be exported
+ *   am_peer_export / open / close   64-byte HIP IPC handle <-> mapped pointer in another process of the node
+ *   am_peer_copy              asynchronous device-to-device copy on `stream` (copy engines, no CU)
+ *   am_peer_signal            *flag = value (system-scope release) after everything earlier on `stream`
+ *   am_peer_wait              holds `stream` until (int32)(*flag - value) >= 0; gives up after ~20 s and sets *fault_word */
+int am_peer_alloc(size_t bytes, void** dev_ptr);
+int am_peer_free(void* dev_ptr);
+int am_peer_export(void* dev_ptr, uint8_t* handle64);
+int am_peer_open(const uint8_t* handle64, void** dev_ptr);
+int am_peer_close(void* dev_ptr);
+int am_peer_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int am_peer_signal(uint32_t* flag_dev, uint32_t value, void* stream);
+int am_peer_wait(const uint32_t* flag_dev, uint32_t value, uint32_t* fault_word_dev, void* stream);
+
 /* small fused elementwise ops */
 int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream);
 int am_bf16_to_f32(const uint16_t* x, float* y, size_t n, void* stream);

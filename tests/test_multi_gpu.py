@@ -22,12 +22,12 @@ def _free_port():
     return p
 
 
-def _run(world, extra=()):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(world, extra=(), tool="mgpu_selftest", env_extra=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "mgpu_selftest.py"), *extra]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", f"{tool}.py"), *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "[mgpu_selftest] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and f"[{tool}] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
 
@@ -44,3 +44,22 @@ def test_short_window_falls_back_to_replicas():
     if not torch.cuda.is_available() or torch.cuda.device_count() < 4:
         pytest.skip("needs 4 GPUs")
     _run(4, ("--frames", "7"))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_copy_engine_exchange_across_processes_on_one_device(world):
+    """The copy-engine exchange back-end (sharding.PeerExchange; ACTIONMESH_AMD_EXCHANGE=peer): `world` processes share ONE
+    GPU, so this runs on the single-GPU boxes too - IPC-mapped gather buffers, SDMA pushes and the arrived / consumed flag
+    protocol between real processes, three forwards in a row, against the unsharded forward."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _run(world, ("--same-device",), tool="peer_selftest")
+    print(out.strip().splitlines()[-2])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_copy_engine_exchange_on_real_ranks(world):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run(world, tool="peer_selftest")
+    _run(world, env_extra={"ACTIONMESH_AMD_EXCHANGE": "peer"})          # the same back-end under HipDenoiser + RCCL control plane

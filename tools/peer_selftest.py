@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Two (or more) PROCESSES drive the copy-engine exchange back-end (sharding.PeerExchange: IPC-shared gather buffers, SDMA
+pushes, stream-ordered sequence flags) through the frame-sharded forward; the control plane is gloo, so it also runs with
+every rank on ONE device (`--same-device`: the single-GPU boxes of the build pool - a real cross-process exchange on real
+hardware, only without xGMI in between).  Rank 0 also runs the unsharded forward and compares.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/peer_selftest.py --same-device
+"""
+import argparse
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--tokens", type=int, default=511)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--forwards", type=int, default=3)
+    a = ap.parse_args()
+    from actionmesh_amd import ClassifierFreeGuidance
+    from actionmesh_amd.denoiser import HipEngine, masked_time, rope_tables_host
+    from actionmesh_amd.sharding import FrameShardPlan, PeerExchange, sharded_forward
+    from oracle import denoiser_oracle as O     # synthetic weights only
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local = 0 if a.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    hp = dict(in_channels=64, num_layers=3, num_attention_heads=2, width=256, mlp_ratio=4.0, cross_attention_dim=64,
+              inflated_layers=[0, 1, 2])
+    sd = O.synthetic_state_dict(O.OracleConfig(**{**hp, "inflated_layers": (0, 1, 2)}), seed=3)
+    T, N, S = a.frames, a.tokens, 9
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((1, T, N, 64), generator=g)
+    ctx = torch.randn((1, T, S, 64), generator=g)
+    mask = torch.zeros(1, T); mask[0, 0] = 1
+    fs = torch.arange(T, dtype=torch.float32)[None]
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(x, ctx, mask, fs)
+    B = 2
+    t_bt = masked_time([640.0, 640.0], m_in, B, T)
+    cos, sin = rope_tables_host(f_in, 128)
+
+    plan = FrameShardPlan(T, world, rank)                       # frame sharding only: every rank exchanges with every other
+    eng = HipEngine(hp, sd, dev, B, plan.frames_local, N, S, world=world, rank=rank,
+                    kv_factory=lambda nbytes: PeerExchange(dist.group.WORLD, plan, nbytes, dev))
+    eng.set_context(plan.slice_frames(c_in.to(dev)), cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64),
+                    sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64))
+    tl = plan.frames_local
+    t_local = [t_bt[b * T + rank * tl + j] for b in range(B) for j in range(tl)]
+    outs = []
+    for _ in range(a.forwards):                                  # several forwards: the consumed / arrived sequence must keep turning
+        v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
+        torch.cuda.synchronize(dev)
+        outs.append(v_local.float().cpu())
+    assert not eng.exchange.faulted(), "a flag wait gave up"
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
+    parts = [torch.empty_like(outs[0]) for _ in range(world)]
+    dist.all_gather(parts, outs[0])
+    if rank == 0:
+        v = torch.cat(parts, dim=1)
+        ref_eng = HipEngine(hp, sd, dev, B, T, N, S)
+        ref_eng.set_context(c_in.to(dev), cos, sin)
+        ref = ref_eng.forward(x_in.to(dev), t_bt).float().cpu()
+        r = float((v - ref).norm() / ref.norm())
+        print(f"[peer_selftest] world {world} ({'one device' if a.same_device else 'one device per rank'}): copy-engine exchange, "
+              f"sharded vs unsharded rel-L2 {r:.3e}", flush=True)
+        assert torch.isfinite(v).all() and r < 1e-2, r
+        ref_eng.close()
+        print("[peer_selftest] ok", flush=True)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

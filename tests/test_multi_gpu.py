@@ -27,7 +27,11 @@ def _run(world, extra=(), tool="mgpu_selftest", env_extra=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tools", f"{tool}.py"), *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and f"[{tool}] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    if r.returncode != 0 and "AssertionError" not in r.stderr and "RuntimeError" not in r.stderr:
+        # a rendezvous / launcher hiccup (port reuse between back-to-back torchruns), not a verdict of the tool: once more
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and f"[{tool}] ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     return r.stdout
 
 

@@ -49,6 +49,21 @@ __global__ __launch_bounds__(256) void timestep_sinusoid_kernel(const float* __r
   out[(int64_t)r * C + half + i] = f2bf(cosf(arg));
 }
 
+// h[r][c] = bf16(h[r][c] + bias[c]) over `rows` rows: what `h + to_out(attention)` is when the attention output is exactly 0
+// (the GEMM epilogue rounds acc = bias to bf16 - the bias is stored already rounded - and adds the bf16 residual).
+__global__ __launch_bounds__(256) void add_bias_rows_kernel(bf16_t* __restrict__ h, const float* __restrict__ bias, int64_t n8, int C8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8) * 8;
+    u32x4_t v = *reinterpret_cast<const u32x4_t*>(h + i * 8);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + c), b1 = *reinterpret_cast<const f32x4_t*>(bias + c + 4);
+    v[0] = pack_bf2(bflo(v[0]) + rbf(b0[0]), bfhi(v[0]) + rbf(b0[1]));
+    v[1] = pack_bf2(bflo(v[1]) + rbf(b0[2]), bfhi(v[1]) + rbf(b0[3]));
+    v[2] = pack_bf2(bflo(v[2]) + rbf(b1[0]), bfhi(v[2]) + rbf(b1[1]));
+    v[3] = pack_bf2(bflo(v[3]) + rbf(b1[2]), bfhi(v[3]) + rbf(b1[3]));
+    *reinterpret_cast<u32x4_t*>(h + i * 8) = v;
+  }
+}
+
 // aggregate_cfg (guidance.py:95-118) in bf16 + Euler step + masked write
 // (scheduler.py:238-248).  dtype flow per SURVEY.md App. C: every bf16 op result
 // is rounded to bf16; dt * v is rounded to bf16 before the fp32 latent add.
@@ -73,6 +88,14 @@ __global__ __launch_bounds__(256) void flow_step_kernel(FlowArgs a) {
 }
 
 }  // namespace
+
+int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream) {      // internal (am_model.hip)
+  const int64_t n8 = rows * (C / 8);
+  const int64_t blocks = (n8 + 255) / 256;
+  hipLaunchKernelGGL(add_bias_rows_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, h, bias, n8, C / 8);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
 
 extern "C" int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream) {
   AM_CHECK(x && y && n > 0, "am_f32_to_bf16: bad args");

@@ -12,6 +12,8 @@
 
 #include "am_common.h"
 
+int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream);    // am_elementwise.hip
+
 namespace {
 constexpr int HD = 128;
 inline int pad_to(int64_t x, int m) { return (int)round_up(x, m); }
@@ -54,6 +56,8 @@ struct am_model {
   float *tdev = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
 
   // per-window / per-forward state
+  std::vector<uint8_t> ctx_zero;   // am_set_branch_hints: batch rows whose context is identically zero
+  bool shared_prefix = false;      // am_set_branch_hints: all batch rows share hidden_states and t_bt
   bool ctx_set = false;
   int ctxB = 0, ctxT = 0, ctxS = 0;
   bool in_forward = false;
@@ -363,6 +367,18 @@ extern "C" int am_set_context(am_handle h, const float* ctx_dev, int B, int T, i
     AM_TRY(am_head_post(&hp, st));
   }
   h->ctx_set = true; h->ctxB = B; h->ctxT = T; h->ctxS = S;
+  h->ctx_zero.assign((size_t)B, 0);
+  h->shared_prefix = false;
+  return AM_OK;
+}
+
+extern "C" int am_set_branch_hints(am_handle h, const uint8_t* ctx_is_zero_host, int shared_prefix) {
+  AM_CHECK(h, "am_set_branch_hints: null handle");
+  if (!h->ctx_set) AM_FAIL(AM_ERR_STATE, "am_set_branch_hints: am_set_context has not been called");
+  h->ctx_zero.assign((size_t)h->ctxB, 0);
+  if (ctx_is_zero_host)
+    for (int b = 0; b < h->ctxB; ++b) h->ctx_zero[b] = ctx_is_zero_host[b] ? 1 : 0;
+  h->shared_prefix = shared_prefix != 0 && h->P == 1 && h->ctxB > 1;
   return AM_OK;
 }
 
@@ -409,10 +425,14 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     AM_TRY(am_layernorm_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, st));
     h->hsrc = h->hwork;
   }
-  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, R, C, 1e-5f, st));      // block.py:138
-  AM_TRY(gemm(st, h->z, C, l.w_qkv, C, nullptr, nullptr, h->qkv, 3 * C, R, 3 * C, C, 0));   // :92-103
+  // exact shortcut (am_set_branch_hints): until the first cross-attention every batch row is the same tensor - layer 0's
+  // self-attention branch runs on row 0 only and am_layer_post_attn copies its result to the other rows
+  const bool shared = i == 0 && h->shared_prefix && !h->has_skip(0);
+  const int64_t Rs = shared ? R / h->B : R;
+  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, Rs, C, 1e-5f, st));      // block.py:138
+  AM_TRY(gemm(st, h->z, C, l.w_qkv, C, nullptr, nullptr, h->qkv, 3 * C, Rs, 3 * C, C, 0));   // :92-103
   am_headpost_args hp = {};
-  hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = R; hp.rows_per_frame = L;
+  hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = Rs; hp.rows_per_frame = L;
   hp.heads = h->H; hp.nparts = 3; hp.kinds[0] = 0; hp.kinds[1] = 1; hp.kinds[2] = 2;
   hp.w_q = l.s_nq; hp.w_k = l.s_nk; hp.eps = 1e-6f;
   hp.rope_cos = h->rope_cos; hp.rope_sin = h->rope_sin;
@@ -474,6 +494,8 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
   const int C = h->C, L = h->L, F = h->F;
   const int64_t R = h->R;
   const float scale = 0.08838834764831845f;   // 1/sqrt(128)
+  const bool shared = i == 0 && h->shared_prefix && !h->has_skip(0);
+  const int64_t Rs = shared ? R / h->B : R;
   // ---- self-attention (attention_processor.py:133-166) ------------------------
   am_attn_args at = {};
   at.Q = h->Qb; at.K = h->Kg; at.Vt = h->Vtg; at.O = h->ao;
@@ -496,6 +518,7 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       at.nseq = h->B * h->T; at.sq = L; at.sq_pad = pad_to(L, 256);
       at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
     }
+    if (shared) at.nseq /= h->B;                           // row 0's sequences only (they come first in every layout)
     if (h->cfg.attn_fp8 && h->inflated(i)) {       // fp8 variant of the long-key-stream attention (configs[4])
       AM_TRY(am_attention_quantize_fp8(&at, h->Q8, h->K8, h->Vt8, st));
       AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
@@ -503,24 +526,48 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       AM_TRY(am_attention_bf16(&at, st));
     }
   }
-  AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, R, C, C, 0));   // to_out + residual (block.py:137)
+  AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, Rs, C, C, 0));   // to_out + residual (block.py:137)
+  if (shared)
+    for (int b = 1; b < h->B; ++b)
+      AM_HIP(hipMemcpyAsync(h->hwork + (size_t)b * Rs * C, h->hwork, (size_t)Rs * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
   h->hsrc = h->hwork;
   // ---- cross-attention to the frame's own context tokens (block.py:146-149) ----
-  AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_x_w, l.ln_x_b, R, C, 1e-5f, st));
-  AM_TRY(gemm(st, h->z, C, l.w_xq, C, nullptr, nullptr, h->qkv, C, R, C, C, 0));
-  am_headpost_args hp = {};
-  hp.X = h->qkv; hp.ldx = C; hp.rows = R; hp.seq_len = L; hp.rows_per_frame = L;
-  hp.heads = h->H; hp.nparts = 1; hp.kinds[0] = 0;
-  hp.w_q = l.x_nq; hp.eps = 1e-6f;
-  hp.out_q = h->Qb; hp.sq_pad = pad_to(L, 256);
-  AM_TRY(am_head_post(&hp, st));
-  am_attn_args ax = {};
-  ax.Q = h->Qb; ax.K = l.kx; ax.Vt = l.vtx; ax.O = h->ao;
-  ax.nseq = h->B * h->T; ax.heads = h->H; ax.sq = L; ax.sq_pad = pad_to(L, 256);
-  ax.sk = h->ctxS; ax.sk_pad = pad_to(h->ctxS, 64); ax.nchunks = 1; ax.chunk_stride = 0;
-  ax.ldo = C; ax.scale = scale; ax.defer_log2 = h->cfg.attn_defer_log2;
-  AM_TRY(am_attention_bf16(&ax, st));
-  AM_TRY(gemm(st, h->ao, C, l.w_xo, C, l.b_xo, h->hwork, h->hwork, C, R, C, C, 0));
+  // Batch rows whose context is identically zero (am_set_branch_hints: the unconditional guidance branch) get the exact
+  // result of the branch - h += to_out bias - instead of the branch; the others run it, one contiguous run of rows at a time.
+  {
+    const int64_t R1 = R / h->B;                       // rows of one batch row
+    for (int b0 = 0; b0 < h->B;) {
+      const bool zero = !h->ctx_zero.empty() && h->ctx_zero[b0];
+      int b1 = b0 + 1;
+      while (b1 < h->B && (!h->ctx_zero.empty() && h->ctx_zero[b1]) == zero) ++b1;
+      const int64_t r0 = (int64_t)b0 * R1, nr = (int64_t)(b1 - b0) * R1;
+      bf16_t* hrun = h->hwork + (size_t)r0 * C;
+      if (zero) {
+        AM_TRY(am_add_bias_rows(hrun, l.b_xo, nr, C, st));
+      } else {
+        AM_TRY(am_layernorm_bf16(hrun, h->z, l.ln_x_w, l.ln_x_b, nr, C, 1e-5f, st));
+        AM_TRY(gemm(st, h->z, C, l.w_xq, C, nullptr, nullptr, h->qkv, C, nr, C, C, 0));
+        am_headpost_args hp = {};
+        hp.X = h->qkv; hp.ldx = C; hp.rows = nr; hp.seq_len = L; hp.rows_per_frame = L;
+        hp.heads = h->H; hp.nparts = 1; hp.kinds[0] = 0;
+        hp.w_q = l.x_nq; hp.eps = 1e-6f;
+        hp.out_q = h->Qb; hp.sq_pad = pad_to(L, 256);
+        AM_TRY(am_head_post(&hp, st));
+        const int Spad = pad_to(h->ctxS, 64);
+        am_attn_args ax = {};
+        ax.Q = h->Qb;
+        ax.K = l.kx + (size_t)b0 * h->T * h->H * Spad * HD;
+        ax.Vt = l.vtx + (size_t)b0 * h->T * h->H * HD * Spad;
+        ax.O = h->ao;
+        ax.nseq = (b1 - b0) * h->T; ax.heads = h->H; ax.sq = L; ax.sq_pad = pad_to(L, 256);
+        ax.sk = h->ctxS; ax.sk_pad = Spad; ax.nchunks = 1; ax.chunk_stride = 0;
+        ax.ldo = C; ax.scale = scale; ax.defer_log2 = h->cfg.attn_defer_log2;
+        AM_TRY(am_attention_bf16(&ax, st));
+        AM_TRY(gemm(st, h->ao, C, l.w_xo, C, l.b_xo, hrun, hrun, C, nr, C, C, 0));
+      }
+      b0 = b1;
+    }
+  }
   // ---- feed-forward (block.py:152; diffusers FeedForward "gelu") ------------------
   AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_f_w, l.ln_f_b, R, C, 1e-5f, st));
   AM_TRY(gemm(st, h->z, C, l.w_ff1, C, l.b_ff1, nullptr, h->ffh, F, R, F, C, 1));

@@ -157,8 +157,11 @@ class HipEngine:
     def kv_buffers(self):
         return self._kv
 
-    def set_context(self, ctx_local: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> None:
-        """ctx_local (B, T_local, S, Dc) fp32 device; cos/sin (B*T_local, 64) fp32 host."""
+    def set_context(self, ctx_local: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                    ctx_zero: Optional[Sequence[bool]] = None, shared_prefix: bool = False) -> None:
+        """ctx_local (B, T_local, S, Dc) fp32 device; cos/sin (B*T_local, 64) fp32 host.
+        `ctx_zero[b]`: the context of batch row b is identically zero; `shared_prefix`: every batch row carries the same
+        hidden_states and t_bt - the two exact shortcuts of am_set_branch_hints (include/actionmesh_amd.h)."""
         B, T, S, _ = ctx_local.shape
         ctx_local = ctx_local.to(self.device, torch.float32).contiguous()
         cos = cos.contiguous(); sin = sin.contiguous()
@@ -166,6 +169,9 @@ class HipEngine:
         with torch.cuda.device(self.device):
             L.check(self.lib.am_set_context(self.handle, ctx_local.data_ptr(), B, T, S,
                                             cos.data_ptr(), sin.data_ptr(), self._stream()), "am_set_context")
+            if (ctx_zero is not None and any(ctx_zero)) or shared_prefix:
+                z = (C.c_uint8 * B)(*[1 if (ctx_zero is not None and ctx_zero[b]) else 0 for b in range(B)])
+                L.check(self.lib.am_set_branch_hints(self.handle, z, 1 if shared_prefix else 0), "am_set_branch_hints")
         self._ctx_keepalive = ctx_local
 
     def begin(self, x_local: torch.Tensor, t_bt_local: List[float]) -> None:
@@ -326,15 +332,23 @@ class HipDenoiser(nn.Module):
         self._window = None
         return self._engine
 
-    def bind_window(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int) -> WindowCache:
-        """Build the step-invariant state for one window: RoPE table and cross-attention K/V."""
+    def bind_window(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int,
+                    ctx_zero: Optional[Sequence[bool]] = None, shared_prefix: bool = False) -> WindowCache:
+        """Build the step-invariant state for one window: RoPE table and cross-attention K/V.
+        `ctx_zero` (per batch row; None = find out with one device reduction) and `shared_prefix` enable the exact shortcuts of
+        am_set_branch_hints; ACTIONMESH_AMD_NO_SHORTCUTS=1 turns both off."""
         B, T, S, _ = context.shape
+        if os.environ.get("ACTIONMESH_AMD_NO_SHORTCUTS", "0") == "1":
+            ctx_zero, shared_prefix = [False] * B, False
+        elif ctx_zero is None:
+            ctx_zero = [not bool(f) for f in context.reshape(B, -1).ne(0).any(dim=1).tolist()]
         plan = self._plan(T, B)
         e = self._ensure_engine(plan.batch_local, plan.frames_local, n_tokens, S, plan)
         cos, sin = rope_tables_host(framestep, HEAD_DIM)        # from the FULL window's framesteps
         cos = plan.slice_local(cos.view(B, T, -1)).reshape(-1, HEAD_DIM // 2)
         sin = plan.slice_local(sin.view(B, T, -1)).reshape(-1, HEAD_DIM // 2)
-        e.set_context(plan.slice_local(context), cos, sin)
+        e.set_context(plan.slice_local(context), cos, sin, ctx_zero=list(ctx_zero)[plan.batch_slice],
+                      shared_prefix=shared_prefix and plan.world == 1)
         self._generation += 1
         self._window = WindowCache(self._generation, context, framestep, n_tokens)
         return self._window

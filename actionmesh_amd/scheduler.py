@@ -78,6 +78,10 @@ class HipSchedulerFlow:
     # fp32 CPU path does not).  False (default) keeps dt in fp32 = the reference's CPU arithmetic; True reproduces the
     # cuda-autocast rounding bit for bit.
     cuda_autocast_dt: bool = False
+    # Not a reference field.  Two EXACT shortcuts of the CFG batch (am_set_branch_hints: bit-identical latents): the unconditional
+    # branch's cross-attention is its to_out bias (zero context, bias-free to_k / to_v), and layer 0's self-attention branch is
+    # computed once for all guidance branches (they carry the same latents and times until the first cross-attention).
+    exact_shortcuts: bool = True
 
     def get_schedule(self):
         """scheduler.py:43-56."""
@@ -137,8 +141,10 @@ class HipSchedulerFlow:
 
         timesteps, distances = self.get_schedule()
         split = self.split_cfg_batch and nb > 1
+        zero = [self.exact_shortcuts and g[0] != 1 for g in branches]
+        shared = self.exact_shortcuts and nb > 1 and all(k == keep[0] for k in keep)
         if not split:
-            diffusion_model.bind_window(ctx_b, fs_b, N)
+            diffusion_model.bind_window(ctx_b, fs_b, N, ctx_zero=zero, shared_prefix=shared)
         it = range(self.num_inference_steps)
         if not disable_prog:
             from tqdm import tqdm
@@ -156,7 +162,7 @@ class HipSchedulerFlow:
                     # per branch: the K/V cache holds one context at a time, as the reference recomputes K/V every call)
                     vs = []
                     for b in range(nb):
-                        diffusion_model.bind_window(ctx_b[b:b + 1], fs_b[b:b + 1], N)
+                        diffusion_model.bind_window(ctx_b[b:b + 1], fs_b[b:b + 1], N, ctx_zero=zero[b:b + 1])
                         vs.append(diffusion_model.forward_host_time(latents, [t * k for k in keep[b]]))
                     v = torch.cat(vs, dim=0)
                 else:

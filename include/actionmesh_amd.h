@@ -94,6 +94,18 @@ int am_weights_missing(am_handle h);
 int am_set_context(am_handle h, const float* ctx_dev, int B, int T_local, int S,
                    const float* rope_cos_host, const float* rope_sin_host, void* stream);
 
+/* Optional, after am_set_context: two EXACT shortcuts of the CFG batch (bit-identical results; the algorithmic flop count
+ * of am_step_flops is unchanged and is what the bench reports against).  Cleared by the next am_set_context.
+ *   ctx_is_zero_host[b] != 0: the context of batch row b is identically zero (the unconditional guidance branch,
+ *       guidance.py:38-93).  to_k / to_v have no bias, so K = V = 0 and the cross-attention output of that row is exactly
+ *       to_out[0].bias: the row's cross-attention branch (norm_x_attn, to_q, head split, SDPA, to_out) is
+ *       replaced by h += bias, and its K/V cache is not built.  NULL = no row is zero.
+ *   shared_prefix != 0: the caller asserts that every batch row carries the same hidden_states and the same t_bt (the sampler
+ *       expands ONE latent tensor over the guidance branches, scheduler.py:215-217).  The rows then differ only from the first
+ *       cross-attention on, so layer 0's skip-free prefix (norm_s_attn, QKV, qk-norm, RoPE, self-attention, to_out + residual)
+ *       is computed for row 0 and copied to the other rows.  Ignored when world_size > 1. */
+int am_set_branch_hints(am_handle h, const uint8_t* ctx_is_zero_host, int shared_prefix);
+
 /* ActionMeshDenoiser.forward (temporal_denoiser.py:151-249), CFG-batched.
  *   x_dev     fp32 (B, T_local, N, Din)
  *   t_bt_host fp32 (B*T_local): per-(b,t) diffusion time AFTER the mask

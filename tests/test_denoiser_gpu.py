@@ -451,3 +451,36 @@ def test_moving_to_cpu_releases_the_engine(dev, golden_dir):
     v1, _ = model.forward(*args())
     torch.cuda.synchronize()
     assert torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_exact_shortcuts_are_bit_identical(dev, golden_dir, name):
+    """am_set_branch_hints: the unconditional branch's cross-attention replaced by its to_out bias, and layer 0's self-attention
+    branch computed once for all guidance branches, must not change a single bit of the latents - per step, in the batched and
+    in the split sampler, and against the 3-branch default guidance (where the branches do NOT share the time token)."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    g, cfg, sd, model, t = _setup(name, golden_dir, dev)
+    steps = int(g["steps"])
+    args = dict(context=t["context"].to(dev), device=dev, mask=t["mask"].to(dev), framestep=t["framestep"].to(dev))
+    for guidance, scales in (([[0, 1], [1, 1]], [7.5]), ([[0, 0], [0, 1], [1, 1]], [2.0, 5.0])):
+        cfgd = ClassifierFreeGuidance(True, guidance, scales)
+        for split in (False, True):
+            outs = []
+            for shortcuts in (True, False):
+                s = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True, split_cfg_batch=split,
+                                     exact_shortcuts=shortcuts)
+                got = [lat.clone() for lat, _ in s._flow_sample(model, cfgd, t["init_latent"].clone().to(dev), **args)]
+                outs.append(torch.stack(got).cpu())
+            assert torch.equal(outs[0], outs[1]), (name, guidance, split, float((outs[0] - outs[1]).abs().max()))
+    # the reference-driven path finds the zero rows itself (one reduction per bind) and must agree with the plain forward
+    import os
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    tt = torch.tensor([float(g["fwd_t"])]).expand(2)
+    v1, _ = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+    os.environ["ACTIONMESH_AMD_NO_SHORTCUTS"] = "1"
+    try:
+        v0, _ = model.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+    finally:
+        del os.environ["ACTIONMESH_AMD_NO_SHORTCUTS"]
+    assert torch.equal(v0, v1)

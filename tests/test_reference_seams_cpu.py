@@ -77,7 +77,11 @@ class StandInEngine:
     def close(self):
         pass
 
-    def set_context(self, ctx_local, cos, sin):
+    def set_context(self, ctx_local, cos, sin, ctx_zero=None, shared_prefix=False):
+        # the stand-in ignores the exact-shortcut hints (HipEngine forwards them to am_set_branch_hints); what reaches it must
+        # describe the context it is given
+        assert ctx_zero is None or [bool(z) for z in ctx_zero] == [not bool(c.any()) for c in ctx_local]
+        assert not shared_prefix
         self.ctx = ctx_local.clone()
         self.cos, self.sin = cos.repeat_interleave(2, dim=1), sin.repeat_interleave(2, dim=1)
         self.binds += 1

@@ -627,8 +627,7 @@ int launch(const am_attn_args* a, void* stream) {
   constexpr bool BALANCED = MAIN == 1;
   const bool use64 = MAIN == 2 || (MAIN == 3 && ceil_div(a->sk, KVBLK) * a->nchunks >= 16);
   using G = Geo<NW, NSUB>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  AM_ONCE_PER_DEVICE({
     if (BALANCED)
       AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_balanced_kernel<DEFER>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUB_B));
@@ -636,8 +635,7 @@ int launch(const am_attn_args* a, void* stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true, NW, NSUB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
-    attr_set = true;
-  }
+  });
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   const int all_supers = ceil_div(tiles_per_chunk, NSUB) * a->nchunks;
   const int nblk = ceil_div(a->sq, G::QBLK);

@@ -802,23 +802,20 @@ extern "C" int am_attention_fallback_count(uint64_t* count) {
 // its workgroups read one word and exit).
 template <int DEFER, int ABL, int STATE, bool LAZY = false>
 static int launch64(const am_attn_args* a, int tiles_per_chunk, int nblk_main, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  AM_ONCE_PER_DEVICE({
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<DEFER, ABL, false, STATE, LAZY>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
-    attr_set = true;
-  }
+  });
   unsigned* flags = nullptr;
   if (LAZY) AM_TRY(lazy_flags((int64_t)nblk_main * a->nseq * a->heads, &flags));
   hipLaunchKernelGGL((attn_fwd64_kernel<DEFER, ABL, false, STATE, LAZY>), dim3(nblk_main, a->nseq * a->heads), dim3(256),
                      NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr, flags, nblk_main);
   if (LAZY && ABL == 0) {
-    static bool attr2_set = false;
-    if (!attr2_set) {
+    AM_ONCE_PER_DEVICE({
       AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd64_kernel<8, 0, false, STATE, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_B));
-      attr2_set = true;
-    }
+    });
+    AM_HIP(hipGetLastError());
     hipLaunchKernelGGL((attn_fwd64_kernel<8, 0, false, STATE, false>), dim3(nblk_main, a->nseq * a->heads), dim3(256),
                        NSTAGE * STAGE_B, (hipStream_t)stream, *a, tiles_per_chunk, (unsigned long long*)nullptr, flags, nblk_main);
   }

@@ -449,16 +449,9 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
            "am_attention_fp8: operands misaligned");
   AM_CHECK(a->ldo % 4 == 0 && a->ldo >= a->heads * HD8, "am_attention_fp8: ldo=%d too small / misaligned", a->ldo);
   AM_CHECK((int64_t)HD8 * a->sk_pad * 1 < (1ll << 31), "am_attention_fp8: sk_pad too large for 32-bit lane offsets");
-  static bool attr_set[64] = {};
-  int dev = 0;
-  AM_HIP(hipGetDevice(&dev));
-  AM_CHECK(dev >= 0 && dev < 64, "am_attention_fp8: device index %d", dev);
-  if (!attr_set[dev]) {
 #define F8_ATTR(A) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
-    F8_ATTR(0); F8_ATTR(1); F8_ATTR(2); F8_ATTR(4); F8_ATTR(8); F8_ATTR(16); F8_ATTR(17); F8_ATTR(6); F8_ATTR(32); F8_ATTR(64); F8_ATTR(40);
+  AM_ONCE_PER_DEVICE({ F8_ATTR(0); F8_ATTR(1); F8_ATTR(2); F8_ATTR(4); F8_ATTR(8); F8_ATTR(16); F8_ATTR(17); F8_ATTR(6); F8_ATTR(32); F8_ATTR(64); F8_ATTR(40); });
 #undef F8_ATTR
-    attr_set[dev] = true;
-  }
   f8_args p;
   p.Q = q8; p.K = k8; p.Vt = vt8; p.O = a->O;
   p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;

@@ -88,6 +88,26 @@ __device__ inline void dma_drain_barrier() {
   __syncthreads();
 }
 
+// hipFuncSetAttribute (dynamic LDS above 64 KiB) is per device: a once-flag per (call site, device), safe from any thread.
+// Usage:  AM_ONCE_PER_DEVICE({ AM_HIP(hipFuncSetAttribute(...)); ... });
+#include <atomic>
+#include <mutex>
+#define AM_ONCE_PER_DEVICE(BODY)                                                             \
+  do {                                                                                       \
+    static std::atomic<bool> done__[64];                                                     \
+    static std::mutex mu__;                                                                  \
+    int dev__ = 0;                                                                           \
+    AM_HIP(hipGetDevice(&dev__));                                                            \
+    AM_CHECK(dev__ >= 0 && dev__ < 64, "device index %d out of range", dev__);               \
+    if (!done__[dev__].load(std::memory_order_acquire)) {                                    \
+      std::lock_guard<std::mutex> lk__(mu__);                                                \
+      if (!done__[dev__].load(std::memory_order_relaxed)) {                                  \
+        BODY                                                                                 \
+        done__[dev__].store(true, std::memory_order_release);                                \
+      }                                                                                      \
+    }                                                                                        \
+  } while (0)
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

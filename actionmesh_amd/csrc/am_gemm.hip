@@ -661,16 +661,14 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
            "am_gemm_bf16: leading dimensions must be multiples of 8 elements (16 B)");
   AM_CHECK(((uintptr_t)a->A1 | (uintptr_t)a->W | (uintptr_t)a->C | (uintptr_t)a->A2 | (uintptr_t)a->residual) % 16 == 0,
            "am_gemm_bf16: operands must be 16-byte aligned");
-  static bool attr_set = false;
-  if (!attr_set) {
+  AM_ONCE_PER_DEVICE({
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
-    attr_set = true;
-  }
+  });
   // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings); bit 9 (0x200) the round-1
   // lockstep main loop of the 256x256 tile (same-box A/B against the ping-pong loop)
   am_gemm_args args = *a;

@@ -218,7 +218,7 @@ class FakeHipEngine(OracleEngine):
     """Same constructor / methods as actionmesh_amd.denoiser.HipEngine, computing with the oracle."""
 
     def __init__(self, hp, state_dict, device, max_batch, frames_local, tokens, ctx_tokens,
-                 world=1, rank=0, attn_defer_log2=8):
+                 world=1, rank=0, attn_defer_log2=8, attn_dtype="bf16", kv_factory=None):
         self.device = torch.device(device)
         self.world, self.rank = world, rank
         self.bounds = (max_batch, frames_local, tokens, ctx_tokens)
@@ -235,7 +235,8 @@ class FakeHipEngine(OracleEngine):
         b = self.bounds
         return B <= b[0] and T <= b[1] and N <= b[2] and S <= b[3]
 
-    def set_context(self, ctx_local, cos, sin):
+    def set_context(self, ctx_local, cos, sin, ctx_zero=None, shared_prefix=False):
+        # the branch hints are exact shortcuts: the oracle stand-in computes the long way
         B, T, S, _ = ctx_local.shape
         plan = FrameShardPlan(T * self.world, self.world, self.rank)     # only frame_world/frame_rank are used
         OracleEngine.__init__(self, self._sd, self._cfg, plan, ctx_local, cos.repeat_interleave(2, -1),

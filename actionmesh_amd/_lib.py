@@ -12,7 +12,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libactionmesh_amd.so")
+# ACTIONMESH_AMD_LIB: another build of the same library (kernel A/B variants, tools/build_variants.sh); never a fallback
+LIB_PATH = os.environ.get("ACTIONMESH_AMD_LIB") or os.path.join(_HERE, "libactionmesh_amd.so")
 ABI_VERSION = 1
 
 

@@ -163,27 +163,6 @@ __device__ __host__ constexpr EsTab32 es_make_tab32(const EsSeq& q, bool pv) {
   return t;
 }
 
-// AM_ES_MOVE > 0 (lazy kernels): the first AM_ES_MOVE steps of block 1's sequence run at the end of the P.V phase (AccVGPR-form
-// MFMAs leave more issue slots beside them than the QK^T phase's arch-VGPR form, tools/ubench/mfma_fillers.hip), behind block
-// 0's steps; the QK^T phase runs the rest.  Steps [first, last) of the sequence, entered at cumulative cost c0 of a phase
-// whose steps cost ctot in total, spread by the gap capacities of es_cap32.
-#ifndef AM_ES_MOVE
-#define AM_ES_MOVE 0
-#endif
-__device__ __host__ constexpr EsTab32 es_make_tab32_sub(const EsSeq& q, bool pv, int first, int last, int c0, int ctot) {
-  int cum[33] = {};
-  for (int i = 0; i < 32; ++i) cum[i + 1] = cum[i] + es_cap32(pv, i);
-  EsTab32 t{};
-  int n = first;
-  const int cfirst = es_cost_before(q, first);
-  for (int i = 0; i <= 32; ++i) {
-    while (n < last && (c0 + es_cost_before(q, n) - cfirst) * cum[32] < cum[i] * ctot) ++n;
-    t.lo[i] = n;
-  }
-  t.lo[32] = last;
-  return t;
-}
-
 template <int ABL>
 struct ExpSumPackT {
   static constexpr EsSeq SEQ = es_make_seq();
@@ -545,111 +524,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     asm volatile("" : "+s"(ok1_prev));
   };
 
-  // ---- one tile, LAZY form with AM_ES_MOVE steps of block 1's softmax moved into the P.V phase.  Block 1's S(g) must then
-  //      be final when phase 1 starts, so its lazy re-base (decided by tile g-1's row sums) runs at the top of the iteration:
-  //      P(g-1) of block 1 computed but not consumed, S(g) accumulated (in flight) - the state block 0's re-base sees at the
-  //      end of an iteration.  The moved steps' packs write p1[0], p1[1] only (AM_ES_MOVE <= 40) and sit behind the k-steps
-  //      that read them. ----
-  auto iteration_lazy_mv = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
-                               u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
-    constexpr int MV = AM_ES_MOVE;
-    static_assert(MV <= 40, "moved packs must stay inside p1[0..1]");
-    stamp(g, 0);
-    if (g > 0) { advance(kcur); advance(vcur); }
-    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    stamp(g, 1);
-    if (ok1_prev != ~0ull) lazy_rebase(1, part1_prev, &p1, s1c);
-    const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
-    const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
-    const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
-    ExpSumPackT<ABL> es, es1;
-    constexpr int CM = es_cost_before(es.SEQ, MV);
-    constexpr EsTab32 ES1 = es_make_tab32_sub(es.SEQ, true, 0, es.SEQ.n, 0, es.SEQ.cost + CM);
-    constexpr EsTab32 ES1B = es_make_tab32_sub(es.SEQ, true, 0, MV, es.SEQ.cost, es.SEQ.cost + CM);
-    constexpr EsTab32 ES2 = es_make_tab32_sub(es.SEQ, false, MV, es.SEQ.n, 0, es.SEQ.cost - CM);
-    static_assert(ES1B.lo[16] == 0, "block 1's moved steps must start behind the k-steps that read p1[0], p1[1]");
-    auto bf = [](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
-    auto steps1 = [&](int gap) __attribute__((always_inline)) {
-      if (ABL & (8 | 32)) return;
-#pragma unroll
-      for (int n = ES1.lo[gap]; n < ES1.lo[gap + 1]; ++n) es.step(n, s0[0], s0[1], p0n);
-#pragma unroll
-      for (int n = ES1B.lo[gap]; n < ES1B.lo[gap + 1]; ++n) es1.step(n, s1c[0], s1c[1], p1);
-    };
-    // ===== phase 1: O += V^T(g-1) P^T(g-1) || softmax of block 0, then the head of block 1's; K(g+3) DMA; K(g+1) prefetch =====
-    stamp(g, 2);
-    es.init();
-    es1.init();
-    FENCE();
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int gap = (kk * 4 + d) * 2;
-        pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
-        POST_PV();
-        if (kk == 0) dma_k(d);
-        if (d < 2) {
-          if (kk < 3) vf[(kk + 1) & 1][2 * d] = v_frag(v_st, 2 * d, kk + 1);
-          else kf[d][0] = k_frag(k_st, 0, d);
-        }
-        steps1(gap);
-        FENCE();
-        pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
-        POST_PV();
-        if (d < 2) {
-          if (kk < 3) vf[(kk + 1) & 1][2 * d + 1] = v_frag(v_st, 2 * d + 1, kk + 1);
-          else kf[d][1] = k_frag(k_st, 1, d);
-        }
-        steps1(gap + 1);
-        FENCE();
-      }
-      HOLD4(vf[kk & 1][0], vf[kk & 1][1], vf[kk & 1][2], vf[kk & 1][3]);
-      if (kk == 0) stamp(g, 3);
-    }
-    stamp(g, 4);
-    const float part0 = es.total();
-    l_run[0] += part0;
-    uint64_t ok0 = __builtin_amdgcn_ballot_w64(part0 <= LAZY_T);
-    asm volatile("" : "+s"(ok0));
-    // ===== phase 2: S(g+1) = K(g+1) Q^T || the rest of block 1's softmax; V^T(g+2) DMA; V^T(g) prefetch =====
-    FENCE();
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int gap = (ks * 2 + kb) * 2;
-        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks % 3][kb], negm[0]);
-        else qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
-        POST_QK();
-        if (ks < 2) dma_v(ks * 2 + kb);
-        if (!(ABL & (8 | 64)))
-#pragma unroll
-          for (int n = ES2.lo[gap]; n < ES2.lo[gap + 1]; ++n) es1.step(n, s1c[0], s1c[1], p1);
-        FENCE();
-        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks % 3][kb], negm[1]);
-        else qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
-        POST_QK();
-        if (ks < 6) kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);
-        else vf[0][(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
-        if (!(ABL & (8 | 64)))
-#pragma unroll
-          for (int n = ES2.lo[gap + 1]; n < ES2.lo[gap + 2]; ++n) es1.step(n, s1c[0], s1c[1], p1);
-        FENCE();
-      }
-      HOLD2(kf[ks % 3][0], kf[ks % 3][1]);
-      if (ks == 1) stamp(g, 5);
-    }
-    stamp(g, 6);
-    const float part1 = es1.total();
-    l_run[1] += part1;
-    // block 0, this tile: P(g) is computed but not consumed, S(g+1) is accumulated
-    if (ok0 != ~0ull) lazy_rebase(0, part0, &p0n, s0);
-    ok1_prev = __builtin_amdgcn_ballot_w64(part1 <= LAZY_T);     // branched on behind the next iteration's barrier
-    part1_prev = part1;
-    asm volatile("" : "+s"(ok1_prev));
-  };
-
   // ---- one tile.  cur = ping-pong set holding S(g) of block 1 and P(g-1) of block 0 ----
   auto iteration = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4],
                        u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
@@ -800,8 +674,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   // ---- main loop, two tiles per trip so the ping-pong sets are compile-time names ----
   auto tile = [&](const int g, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], u32x4_t (&p0c)[4], u32x4_t (&p0n)[4])
       __attribute__((always_inline)) {
-    if constexpr (LAZY && AM_ES_MOVE > 0) iteration_lazy_mv(g, s1c, s1n, p0c, p0n);
-    else if constexpr (LAZY) iteration_lazy(g, s1c, s1n, p0c, p0n);
+    if constexpr (LAZY) iteration_lazy(g, s1c, s1n, p0c, p0n);
     else iteration(g, s1c, s1n, p0c, p0n);
   };
   // Odd tile counts take their extra tile after the loop (peeled in front of it, the two entry paths meet with every

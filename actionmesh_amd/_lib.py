@@ -57,6 +57,15 @@ class AmHeadPostArgs(C.Structure):
     ]
 
 
+class AmNnArgs(C.Structure):
+    _fields_ = [
+        ("points", C.c_void_p), ("n_points", C.c_int64), ("points_bstride", C.c_int64),
+        ("queries", C.c_void_p), ("n_queries", C.c_int64), ("queries_bstride", C.c_int64),
+        ("batch", C.c_int32), ("precise", C.c_int32),
+        ("out_index", C.c_void_p), ("out_d2", C.c_void_p),
+    ]
+
+
 class AmAttnArgs(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
@@ -86,6 +95,8 @@ SYMBOLS = {
     "am_displacement": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "am_attention_fallback_count": (C.c_int, [_P]),
     "am_patchify": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "am_nn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "am_nn_search": (C.c_int, [C.POINTER(AmNnArgs), _P, C.c_size_t, _P]),
     "am_layer_pre_attn": (C.c_int, [_P, C.c_int, _P]),
     "am_layer_attn_local": (C.c_int, [_P, C.c_int, _P]),
     "am_layer_post_attn": (C.c_int, [_P, C.c_int, _P]),

@@ -269,3 +269,33 @@ def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], d
         un = (C.c_uint8 * T)(*[1 if u else 0 for u in unobserved])
     _launch(v, L.lib().am_flow_step, "am_flow_step", v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
                                  un, T, N, D)
+
+
+def nearest_neighbors(points: torch.Tensor, queries: torch.Tensor, precise: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """am_nn_search: for every query its nearest point (exact, brute force).  points (P, 3) or (B, P, 3) fp32, queries
+    (Q, 3) or (B, Q, 3) fp32 (a 2-D operand beside a 3-D one is shared by the batch).  Returns (index int32, SQUARED
+    distance: float64 when `precise` - the KD-tree arithmetic of actionbench/chamfer.py - else float32), shaped like the
+    queries minus the coordinate axis."""
+    _need(points, torch.float32, "points"); _need(queries, torch.float32, "queries")
+    if points.shape[-1] != 3 or queries.shape[-1] != 3 or points.dim() not in (2, 3) or queries.dim() not in (2, 3):
+        raise ValueError(f"nearest_neighbors: expected (..., n, 3) operands, got {tuple(points.shape)} / {tuple(queries.shape)}")
+    batch = max(points.shape[0] if points.dim() == 3 else 1, queries.shape[0] if queries.dim() == 3 else 1)
+    for name, t in (("points", points), ("queries", queries)):
+        if t.dim() == 3 and t.shape[0] != batch:
+            raise ValueError(f"nearest_neighbors: {name} batch {t.shape[0]} != {batch}")
+    P, Q = points.shape[-2], queries.shape[-2]
+    if P == 0 or Q == 0:
+        raise ValueError("nearest_neighbors: empty point cloud")
+    out_shape = (batch, Q) if (points.dim() == 3 or queries.dim() == 3) else (Q,)
+    idx = torch.empty(out_shape, dtype=torch.int32, device=queries.device)
+    d2 = torch.empty(out_shape, dtype=torch.float64 if precise else torch.float32, device=queries.device)
+    lib = L.lib()
+    need = lib.am_nn_workspace_bytes(P, Q, batch, 1 if precise else 0)
+    ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=queries.device)
+    a = L.AmNnArgs()
+    a.points, a.n_points, a.points_bstride = points.data_ptr(), P, (P * 3 if points.dim() == 3 else 0)
+    a.queries, a.n_queries, a.queries_bstride = queries.data_ptr(), Q, (Q * 3 if queries.dim() == 3 else 0)
+    a.batch, a.precise = batch, 1 if precise else 0
+    a.out_index, a.out_d2 = idx.data_ptr(), d2.data_ptr()
+    _launch(queries, lib.am_nn_search, "am_nn_search", C.byref(a), ws.data_ptr(), need)
+    return idx, d2

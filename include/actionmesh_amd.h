@@ -273,6 +273,29 @@ int am_displacement(const uint16_t* logits, int ld, int64_t rows, int out_dim, f
 int am_patchify(const float* pixels, int frames, int channels, int height, int width, int patch, uint16_t* out,
                 int ld_out, void* stream);
 
+/* ActionBench quality gate (actionbench/chamfer.py:13-86, actionbench/icp.py:94): exact nearest-neighbour
+ * search, the arithmetic of scipy.spatial.KDTree(points).query(queries) and of pytorch3d's chamfer_distance.
+ *   points  (batch, n_points, 3) fp32, batch stride points_bstride ELEMENTS (0 = one cloud shared by every batch entry);
+ *   queries (batch, n_queries, 3) fp32 likewise;
+ *   out_index (batch, n_queries) int32 = argmin_p |q - p|^2, ties -> lowest index;
+ *   out_d2    (batch, n_queries)       = that minimum SQUARED distance, double when precise != 0 (fp64 arithmetic,
+ *             ((dx*dx) + (dy*dy)) + dz*dz without contraction: bit-identical to the reference's KD-tree), else float.
+ * am_nn_workspace_bytes() bytes of device scratch (may be 0) must be passed for the same (n_points, n_queries, batch, precise). */
+typedef struct {
+  const float* points;
+  int64_t n_points;
+  int64_t points_bstride;
+  const float* queries;
+  int64_t n_queries;
+  int64_t queries_bstride;
+  int32_t batch;
+  int32_t precise;
+  int32_t* out_index;
+  void* out_d2;
+} am_nn_args;
+size_t am_nn_workspace_bytes(int64_t n_points, int64_t n_queries, int batch, int precise);
+int am_nn_search(const am_nn_args* args, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header(tmp_path):
     """ctypes mirrors vs the C header, measured by compiling a probe with gcc against include/."""
     import subprocess
     structs = {"am_config": _lib.AmConfig, "am_gemm_args": _lib.AmGemmArgs,
-               "am_headpost_args": _lib.AmHeadPostArgs, "am_attn_args": _lib.AmAttnArgs}
+               "am_headpost_args": _lib.AmHeadPostArgs, "am_attn_args": _lib.AmAttnArgs, "am_nn_args": _lib.AmNnArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "actionmesh_amd.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

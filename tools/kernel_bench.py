@@ -138,6 +138,13 @@ def main():
                 ms = timeit(fn, a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} torch op sequence (library GEMM + elementwise): {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             del A, W, out, res
+    if "nn" in only:      # ActionBench nearest-neighbour search (am_nn_search): metric shape and the ICP inner-loop shape
+        for P, Q, Bn, precise in ((100_000, 100_000, 1, True), (100_000, 10_000, 1, True), (100_000, 100_000, 1, False), (10_000, 10_000, 24, False)):
+            pts = torch.randn((Bn, P, 3), device=dev, generator=g); qry = torch.randn((Bn, Q, 3), device=dev, generator=g)
+            ms = timeit(lambda: ops.nearest_neighbors(pts, qry, precise=precise), a.reps)
+            # 8 arithmetic lane-operations per pair (3 sub, 3 mul, 2 add) + compare / select
+            print(f"nn_search  P={P} Q={Q} batch={Bn} {'fp64' if precise else 'fp32'}: {ms:8.3f} ms  {Bn * P * Q / ms / 1e6:8.1f} G pairs/s  "
+                  f"{8.0 * Bn * P * Q / ms / 1e9:7.2f} TFLOP/s")
     if "ln" in only:
         x = rnd(R, C); w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev); y = torch.empty_like(x)
         ms = timeit(lambda: ops.layernorm(x, w, b, out=y), a.reps)

@@ -59,3 +59,138 @@ def compute_motion_chamfer_score(preds, gts, device=None) -> float:
     d1 = np.linalg.norm(diff1, axis=-1).mean(axis=0)
     d2 = np.linalg.norm(diff2, axis=-1).mean(axis=0)
     return float(np.mean(d1) + np.mean(d2))
+
+
+# ---------------------------------------------------------------------------------------------------------------- ICP
+# actionbench/icp.py + benchmark.py.  The reference leans on pytorch3d (chamfer_distance, rotation_6d_to_matrix,
+# euler_angles_to_matrix, Transform3d), which is not installable offline: the few formulas used are restated below from
+# their published definitions (parity of this half is therefore UNPINNED - see oracle/actionbench_oracle.py - while the
+# Chamfer metrics above are pinned to the reference's own code).  The 24 x 200 x 2 nearest-neighbour searches of
+# gradient_icp run as batched am_nn_search launches (fp32, like pytorch3d's knn); the gradient flows through the matched
+# pairs exactly as in pytorch3d's chamfer_distance (indices are constants of the backward pass).
+
+def _axis_rotation(axis: str, angle: torch.Tensor) -> torch.Tensor:
+    c, s, one, zero = torch.cos(angle), torch.sin(angle), torch.ones_like(angle), torch.zeros_like(angle)
+    flat = {"X": (one, zero, zero, zero, c, -s, zero, s, c),
+            "Y": (c, zero, s, zero, one, zero, -s, zero, c),
+            "Z": (c, -s, zero, s, c, zero, zero, zero, one)}[axis]
+    return torch.stack(flat, -1).reshape(angle.shape + (3, 3))
+
+
+def euler_angles_to_matrix(euler_angles: torch.Tensor, convention: str = "XYZ") -> torch.Tensor:
+    """pytorch3d.transforms.euler_angles_to_matrix: R = R_c0(a0) R_c1(a1) R_c2(a2)."""
+    m = [_axis_rotation(c, a) for c, a in zip(convention, torch.unbind(euler_angles, -1))]
+    return m[0] @ m[1] @ m[2]
+
+
+def rotation_6d_to_matrix(d6: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.rotation_6d_to_matrix (Zhou et al. 2019): Gram-Schmidt of the two 3-vectors, rows b1, b2, b1 x b2."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = torch.nn.functional.normalize(a1, dim=-1)
+    b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
+
+
+def canonical_rotation_matrices() -> torch.Tensor:
+    """icp.py:19-51: the 24 axis-aligned orientations."""
+    d = torch.pi / 180
+    azim = torch.tensor([0] * 4 + [90] * 4 + [180] * 4 + [270] * 4 + [0] * 4 + [90] * 4, dtype=torch.float32) * d
+    elev = torch.tensor([0] * 16 + [90] * 2 + [-90] * 2 + [90] * 2 + [-90] * 2, dtype=torch.float32) * d
+    roll = torch.tensor([0, 90, 180, 270] * 4 + [0, 90] * 4, dtype=torch.float32) * d
+    return euler_angles_to_matrix(torch.stack((azim, elev, roll), dim=-1), convention="XYZ")
+
+
+class ScaleRotateTranslate:
+    """What icp.py:108-111 returns (Scale(s).compose(Rotate(R), Translate(T)), row-vector convention): p' = (s * p) @ R + T,
+    one transform or a stack of K of them applied to K point clouds."""
+
+    def __init__(self, R: torch.Tensor, T: torch.Tensor, s: torch.Tensor):
+        self.R, self.T, self.s = R.reshape(-1, 3, 3), T.reshape(-1, 3), s.reshape(-1, 3)
+
+    def __len__(self) -> int:
+        return self.R.shape[0]
+
+    def stack(self, *others: "ScaleRotateTranslate") -> "ScaleRotateTranslate":
+        items = (self,) + others
+        return ScaleRotateTranslate(torch.cat([t.R for t in items]), torch.cat([t.T for t in items]), torch.cat([t.s for t in items]))
+
+    def transform_points(self, points: torch.Tensor) -> torch.Tensor:
+        p = points if points.dim() == 3 else points[None]
+        out = (self.s[:, None, :] * p) @ self.R + self.T[:, None, :]
+        return out if points.dim() == 3 else out[0]
+
+
+def chamfer_distance_sq(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.loss.chamfer_distance(x, y, batch_reduction=None)[0]: per batch entry, mean_i min_j |x_i - y_j|^2 +
+    mean_j min_i |y_j - x_i|^2; differentiable w.r.t. both clouds through the matched pairs."""
+    with torch.no_grad():
+        ixy, _ = ops.nearest_neighbors(y.detach().contiguous(), x.detach().contiguous(), precise=False)
+        iyx, _ = ops.nearest_neighbors(x.detach().contiguous(), y.detach().contiguous(), precise=False)
+    gx = torch.gather(y, 1, ixy.long()[..., None].expand(-1, -1, 3))
+    gy = torch.gather(x, 1, iyx.long()[..., None].expand(-1, -1, 3))
+    return (x - gx).pow(2).sum(-1).mean(1) + (y - gy).pow(2).sum(-1).mean(1)
+
+
+@torch.enable_grad()
+def gradient_icp(pc_pred: torch.Tensor, pc_gt: torch.Tensor, lr: float = 0.01, n_iter: int = 200, _chamfer=None) -> ScaleRotateTranslate:
+    """icp.py:54-111: the similarity (anisotropic scale) transform from pc_pred (P, 3) to pc_gt (Q, 3): Adam on a 6-D rotation,
+    a translation and a per-axis scale from 24 canonical starting orientations at once; the best loss seen wins."""
+    chamfer = chamfer_distance_sq if _chamfer is None else _chamfer
+    device = pc_pred.device
+    R_init = canonical_rotation_matrices().to(device)
+    n_rots = len(R_init)
+    pred = pc_pred.detach().float()[None].expand(n_rots, -1, -1)
+    gt = pc_gt.detach().float()[None].expand(n_rots, -1, -1).contiguous()
+    T = torch.nn.Parameter(torch.zeros(n_rots, 3, device=device))
+    R_6d = torch.nn.Parameter(torch.tensor([[1.0, 0.0, 0.0, 0.0, 1.0, 0.0]], device=device).repeat(n_rots, 1))
+    s = torch.nn.Parameter(torch.ones(n_rots, 3, device=device))
+    opt = torch.optim.Adam(params=[T, R_6d, s], lr=lr)
+    best_loss, best = float("inf"), None
+    for _ in range(n_iter):
+        opt.zero_grad()
+        R = R_init @ rotation_6d_to_matrix(R_6d)
+        loss = chamfer(s[:, None] * pred @ R + T[:, None], gt)
+        loss.mean().backward()
+        opt.step()
+        min_loss, idx = loss.detach().min(0)
+        if min_loss.item() < best_loss:
+            best_loss = min_loss.item()
+            best = (R[idx:idx + 1].detach().clone(), T[idx:idx + 1].detach().clone(), s[idx:idx + 1].detach().clone())
+    out = ScaleRotateTranslate(*best)
+    out.loss = best_loss
+    return out
+
+
+def sample_point_cloud(point_cloud: torch.Tensor, n_pts: int, seed: int = 44) -> torch.Tensor:
+    """actionbench/sample_point_cloud.py:12-36: one RandomState(seed) permutation shared by all timesteps."""
+    n_src = point_cloud.shape[1]
+    if n_src <= n_pts:
+        return point_cloud
+    idx = torch.from_numpy(np.random.RandomState(seed=seed).permutation(n_src)[:n_pts]).long()
+    return point_cloud[:, idx.to(point_cloud.device)]
+
+
+def compute_chamfer_3d_4d(gt_pc: torch.Tensor, pred_pc: torch.Tensor, device="cuda:0", is_4D: bool = False,
+                          pred_pc_4D: Optional[torch.Tensor] = None, n_pts_icp: int = 10_000, seed: int = 44,
+                          n_iter: int = 200) -> Tuple[float, float, float]:
+    """benchmark.py:67-153 from point clouds: gt_pc (T, N, 3), pred_pc (T, M, 3) sampled per frame, pred_pc_4D (T, M, 3)
+    sampled with frame-to-frame correspondence (is_4D).  (The reference samples these from trimesh objects with trimesh /
+    pytorch3d samplers - sample_mesh.py - whose random streams are theirs; hand it the same clouds and the rest follows
+    benchmark.py line by line.)  Returns (cd_3d: per-frame ICP, cd_4d: first-frame ICP, cd_motion)."""
+    n_ts = pred_pc.shape[0]
+    pred_pc_icp = sample_point_cloud(pred_pc, n_pts=n_pts_icp, seed=seed)
+    gt_pc_icp = sample_point_cloud(gt_pc, n_pts=n_pts_icp, seed=seed)
+    pred_pc, gt_pc = _dev(pred_pc, device), _dev(gt_pc, device)
+    pred_pc_icp, gt_pc_icp = _dev(pred_pc_icp, device), _dev(gt_pc_icp, device)
+    icp_list = [gradient_icp(pc_gt=gt_pc_icp[k], pc_pred=pred_pc_icp[k], lr=0.01, n_iter=n_iter) for k in range(n_ts)]
+    icp_3d = icp_list[0].stack(*icp_list[1:])
+    icp_u4d = gradient_icp(pc_gt=gt_pc_icp[0], pc_pred=pred_pc_icp[0], lr=0.01, n_iter=n_iter)
+    aligned_3d, aligned_u4d = icp_3d.transform_points(pred_pc), icp_u4d.transform_points(pred_pc)
+    cd_3d = np.mean([compute_chamfer_score(gt=gt_pc[k], pred=aligned_3d[k]) for k in range(n_ts)])
+    cd_4d = np.mean([compute_chamfer_score(gt=gt_pc[k], pred=aligned_u4d[k]) for k in range(n_ts)])
+    cd_motion = 0.0
+    if is_4D:
+        if pred_pc_4D is None:
+            raise ValueError("is_4D needs pred_pc_4D (the synchronized sampling of the predicted meshes)")
+        cd_motion = compute_motion_chamfer_score(preds=icp_u4d.transform_points(_dev(pred_pc_4D, device)), gts=gt_pc)
+    return float(cd_3d), float(cd_4d), float(cd_motion)

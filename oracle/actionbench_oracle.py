@@ -48,3 +48,65 @@ def compute_motion_chamfer_score(preds, gts) -> float:
     d1 = np.linalg.norm(preds[:, idx_gt_to_pred, :] - gts, axis=-1).mean(axis=0)
     d2 = np.linalg.norm(gts[:, idx_pred_to_gt, :] - preds, axis=-1).mean(axis=0)
     return float(np.mean(d1) + np.mean(d2))
+
+
+# ---------------------------------------------------------------------------------------------------------------- ICP
+# actionbench/icp.py restated on CPU torch.  PARITY UNPINNED for this half: the reference computes with pytorch3d
+# (chamfer_distance, rotation_6d_to_matrix, euler_angles_to_matrix, Transform3d), which is neither vendored nor installable
+# offline, and the reference ships no test vectors for it; the pytorch3d functions are restated from their published
+# definitions (pytorch3d v0.7 docs: chamfer_distance = mean squared nearest-neighbour distance in both directions;
+# rotation_6d_to_matrix = Gram-Schmidt rows; euler_angles_to_matrix("XYZ") = Rx Ry Rz).
+import torch  # noqa: E402
+
+
+def chamfer_distance_sq(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """(N, P, 3), (N, Q, 3) -> (N,): autograd differentiates straight through the min."""
+    d = (x[:, :, None, :] - y[:, None, :, :]).pow(2).sum(-1)
+    return d.min(dim=2).values.mean(1) + d.min(dim=1).values.mean(1)
+
+
+def _rot(axis, a):
+    c, s, o, z = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+    m = {"X": (o, z, z, z, c, -s, z, s, c), "Y": (c, z, s, z, o, z, -s, z, c), "Z": (c, -s, z, s, c, z, z, z, o)}[axis]
+    return torch.stack(m, -1).reshape(a.shape + (3, 3))
+
+
+def canonical_rotation_matrices() -> torch.Tensor:
+    """icp.py:19-51"""
+    d = torch.pi / 180
+    azim = torch.tensor([0] * 4 + [90] * 4 + [180] * 4 + [270] * 4 + [0] * 4 + [90] * 4, dtype=torch.float32) * d
+    elev = torch.tensor([0] * 16 + [90] * 2 + [-90] * 2 + [90] * 2 + [-90] * 2, dtype=torch.float32) * d
+    roll = torch.tensor([0, 90, 180, 270] * 4 + [0, 90] * 4, dtype=torch.float32) * d
+    return _rot("X", azim) @ _rot("Y", elev) @ _rot("Z", roll)
+
+
+def rotation_6d_to_matrix(d6):
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = a1 / a1.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = b2 / b2.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
+
+
+def gradient_icp(pc_pred, pc_gt, lr=0.01, n_iter=200):
+    """icp.py:54-111 -> (R (1,3,3), T (1,3), s (1,3), best loss): p' = (s * p) @ R + T"""
+    with torch.enable_grad():
+        R_init = canonical_rotation_matrices()
+        n = len(R_init)
+        pred, gt = pc_pred[None].expand(n, -1, -1), pc_gt[None].expand(n, -1, -1)
+        T = torch.nn.Parameter(torch.zeros(n, 3))
+        R6 = torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0, 1.0, 0]]).repeat(n, 1))
+        s = torch.nn.Parameter(torch.ones(n, 3))
+        opt = torch.optim.Adam([T, R6, s], lr=lr)
+        best_loss, best = float("inf"), None
+        for _ in range(n_iter):
+            opt.zero_grad()
+            R = R_init @ rotation_6d_to_matrix(R6)
+            loss = chamfer_distance_sq(s[:, None] * pred @ R + T[:, None], gt)
+            loss.mean().backward()
+            opt.step()
+            m, i = loss.detach().min(0)
+            if m.item() < best_loss:
+                best_loss = m.item()
+                best = (R[i:i + 1].detach().clone(), T[i:i + 1].detach().clone(), s[i:i + 1].detach().clone())
+    return best + (best_loss,)

@@ -135,3 +135,58 @@ def test_nn_rejects_bad_shapes(dev):
         ops.nearest_neighbors(torch.zeros((2, 4, 3), device=dev), torch.zeros((3, 2, 3), device=dev))
     with pytest.raises(TypeError):
         ops.nearest_neighbors(torch.zeros((4, 3), device=dev, dtype=torch.float64), torch.zeros((2, 3), device=dev))
+
+
+# ---------------------------------------------------------------- ICP half (restated pytorch3d formulas: parity unpinned)
+def test_icp_formulas_cpu():
+    R = AB.canonical_rotation_matrices()
+    assert torch.allclose(R, O.canonical_rotation_matrices(), atol=1e-7)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(24, 3, 3), atol=1e-6) and torch.allclose(torch.det(R), torch.ones(24))
+    assert torch.allclose(R.abs().sum(-1), torch.ones(24, 3), atol=1e-6)           # axis-aligned: signed permutation matrices
+    d6 = torch.randn(7, 6, generator=torch.Generator().manual_seed(0))
+    M6 = AB.rotation_6d_to_matrix(d6)
+    assert torch.allclose(M6, O.rotation_6d_to_matrix(d6), atol=1e-6) and torch.allclose(M6 @ M6.transpose(1, 2), torch.eye(3).expand(7, 3, 3), atol=1e-5)
+    assert torch.allclose(AB.rotation_6d_to_matrix(torch.tensor([[1.0, 0, 0, 0, 1.0, 0]])), torch.eye(3)[None])
+    t = AB.ScaleRotateTranslate(R[5], torch.tensor([1.0, 2, 3]), torch.tensor([2.0, 1, 0.5]))
+    p = torch.randn(11, 3)
+    assert torch.allclose(t.transform_points(p), (torch.tensor([2.0, 1, 0.5]) * p) @ R[5] + torch.tensor([1.0, 2, 3]))
+    st = t.stack(t, t)
+    assert len(st) == 3 and torch.allclose(st.transform_points(p[None].repeat(3, 1, 1))[2], t.transform_points(p))
+    pc = torch.arange(5 * 20 * 3, dtype=torch.float32).reshape(5, 20, 3)
+    sub = AB.sample_point_cloud(pc, 6, seed=44)                                   # sample_point_cloud.py:34-36
+    assert torch.equal(sub, pc[:, torch.from_numpy(np.random.RandomState(44).permutation(20)[:6]).long()])
+    assert AB.sample_point_cloud(pc, 20) is pc
+
+
+@pytest.mark.gpu
+def test_chamfer_loss_and_gradient_match_autograd_through_min(dev):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((3, 400, 3), generator=g, requires_grad=True)
+    y = torch.randn((3, 350, 3), generator=g, requires_grad=True)
+    ref = O.chamfer_distance_sq(x, y)
+    ref.sum().backward()
+    xd, yd = x.detach().to(dev).requires_grad_(), y.detach().to(dev).requires_grad_()
+    got = AB.chamfer_distance_sq(xd, yd)
+    got.sum().backward()
+    assert torch.allclose(got.cpu(), ref, rtol=1e-5) and torch.allclose(xd.grad.cpu(), x.grad, atol=1e-6) and torch.allclose(yd.grad.cpu(), y.grad, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gradient_icp_recovers_a_known_similarity(dev):
+    """an asymmetric cloud, rotated by a canonical orientation plus 12 degrees, scaled anisotropically and shifted: the ICP must
+    bring the aligned Chamfer distance to the noise floor; the CPU restatement run on the same data lands at the same loss"""
+    g = torch.Generator().manual_seed(4)
+    pred = torch.randn((500, 3), generator=g) * torch.tensor([1.0, 0.6, 0.3]) + torch.tensor([0.3, 0.0, 0.0]) * torch.randn((500, 1), generator=g).abs()
+    R_true = AB.canonical_rotation_matrices()[9] @ AB.euler_angles_to_matrix(torch.tensor([0.21, -0.1, 0.05]))
+    gt = (torch.tensor([1.1, 0.95, 1.05]) * pred) @ R_true + torch.tensor([0.05, -0.02, 0.03])
+    gt = gt[torch.randperm(500, generator=g)]
+    icp = AB.gradient_icp(pc_pred=pred.to(dev), pc_gt=gt.to(dev), lr=0.01, n_iter=120)
+    aligned = icp.transform_points(pred.to(dev))
+    before = AB.compute_chamfer_score(pred, gt)
+    after = AB.compute_chamfer_score(aligned, gt)
+    assert after < 0.1 * before and icp.loss < 2e-3, (before, after, icp.loss)
+    Rc, Tc, sc, loss_c = O.gradient_icp(pred, gt, lr=0.01, n_iter=120)
+    assert abs(icp.loss - loss_c) <= 0.25 * max(loss_c, 1e-4), (icp.loss, loss_c)          # two fp32 runs of a 120-step optimiser
+    cd3, cd4, cdm = AB.compute_chamfer_3d_4d(gt[None].repeat(2, 1, 1), pred[None].repeat(2, 1, 1), device=dev, is_4D=True,
+                                             pred_pc_4D=pred[None].repeat(2, 1, 1), n_pts_icp=300, n_iter=60)
+    assert 0 <= cd3 < before and 0 <= cd4 < before and cdm >= 0

@@ -57,6 +57,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 #ifndef AM_A64_POSTFENCE
 #define AM_A64_POSTFENCE 3
 #endif
+#ifndef AM_A64_SADDR
+#define AM_A64_SADDR 1
+#endif
+#ifndef AM_A64_PREP
+#define AM_A64_PREP 1
+#endif
 #define POST_QK() do { if (AM_A64_POSTFENCE & 1) FENCE(); } while (0)
 #define POST_PV() do { if (AM_A64_POSTFENCE & 2) FENCE(); } while (0)
 // Pins a value to this point of the instruction stream: the (empty) volatile asm is ordered with the MFMA asm
@@ -142,7 +148,7 @@ __device__ __host__ constexpr EsTab es_make_tab(const EsSeq& q) {
 #define AM_ES_CAP_DMA 0
 #endif
 #ifndef AM_ES_CAP_READ
-#define AM_ES_CAP_READ 8
+#define AM_ES_CAP_READ 6
 #endif
 struct EsTab32 { int lo[33]; };
 __device__ __host__ constexpr int es_cap32(bool pv, int gap) {
@@ -276,15 +282,47 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
   };
+  // One LDS-DMA piece: 64 lanes x 16 bytes from (wave-uniform base + 32-bit lane offset) to LDS at dst + lane * 16.
+  // AM_A64_SADDR: the scalar-base form of the instruction, written as asm (hipcc selects the 64-bit vector-address form for the
+  // builtin and spends a v_lshl_add_u64 per piece on it); M0 = the wave's LDS base, one wait state before its use.
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)smem);
+  auto dma_piece = [&](const char* src, unsigned lane_off, unsigned char* dst) __attribute__((always_inline)) {
+#if AM_A64_SADDR
+    const unsigned lds = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(dst - smem));      // integer arithmetic: no null-checked address-space cast per piece
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src), "s"(lds) : "memory", "m0");
+#else
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane_off), (lds_ptr_t)dst, 16, 0, 0);
+#endif
+  };
   auto dma_k = [&](int i) __attribute__((always_inline)) {      // piece i of 4 of the next K tile -> ring slot j & 3
     unsigned char* dst = smem + (kcur.j & 3) * STAGE_B + wave * 1024 + i * 4096;
-    const char* src = uniform(k_base + (kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD) * 2);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + k_lane_off), (lds_ptr_t)dst, 16, 0, 0);
+    dma_piece(uniform(k_base + (kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD) * 2), k_lane_off, dst);
   };
   auto dma_v = [&](int i) __attribute__((always_inline)) {
     unsigned char* dst = smem + (vcur.j & 3) * STAGE_B + SUB_B + wave * 1024 + i * 4096;
-    const char* src = uniform(v_base + (vcur.off + (int64_t)vcur.tt * KVBLK) * 2 + i * v_step);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + v_lane_off), (lds_ptr_t)dst, 16, 0, 0);
+    dma_piece(uniform(v_base + (vcur.off + (int64_t)vcur.tt * KVBLK) * 2 + i * v_step), v_lane_off, dst);
+  };
+
+  // AM_A64_PREP (lazy kernel): a piece's scalar address arithmetic runs one gap ahead of its issue, so the DMA gaps - the ones
+  // over their issue budget - hold nothing but the M0 write and the instruction itself.
+  const char* k_src_n = k_base;
+  const char* v_src_n = v_base;
+  unsigned k_lds_n = 0, v_lds_n = 0;
+  auto k_prep = [&](int i) __attribute__((always_inline)) {
+    k_lds_n = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((kcur.j & 3) * STAGE_B + wave * 1024 + i * 4096));
+    k_src_n = uniform(k_base + (kcur.off + (int64_t)kcur.tt * (KVBLK * HD) + i * 16 * HD) * 2);
+    asm volatile("" : "+s"(k_lds_n), "+s"(k_src_n));
+  };
+  auto v_prep = [&](int i) __attribute__((always_inline)) {
+    v_lds_n = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)((vcur.j & 3) * STAGE_B + SUB_B + wave * 1024 + i * 4096));
+    v_src_n = uniform(v_base + (vcur.off + (int64_t)vcur.tt * KVBLK) * 2 + i * v_step);
+    asm volatile("" : "+s"(v_lds_n), "+s"(v_src_n));
+  };
+  auto k_issue = [&]() __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(k_lane_off), "s"(k_src_n), "s"(k_lds_n) : "memory", "m0");
+  };
+  auto v_issue = [&]() __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_lane_off), "s"(v_src_n), "s"(v_lds_n) : "memory", "m0");
   };
 
   // fragment read offsets (bytes) inside a ring stage
@@ -436,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
                             u32x4_t (&p0n)[4]) __attribute__((always_inline)) {
     stamp(g, 0);
     if (g > 0) { advance(kcur); advance(vcur); }
+    if (AM_A64_PREP) { k_prep(0); v_prep(0); }
     if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     stamp(g, 1);
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
@@ -455,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         const int gap = (kk * 4 + d) * 2;
         pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
         POST_PV();
-        if (kk == 0) dma_k(d);                                  // one LDS-DMA piece per MFMA pair
+        if (kk == 0) { if (AM_A64_PREP) k_issue(); else dma_k(d); }      // one LDS-DMA piece per MFMA pair
         if (d < 2) {                                            // next fragments in gaps 0..3 of the step: landed by its end
           if (kk < 3) vf[(kk + 1) & 1][2 * d] = v_frag(v_st, 2 * d, kk + 1);
           else kf[d][0] = k_frag(k_st, 0, d);
@@ -466,6 +505,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         FENCE();
         pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
         POST_PV();
+        if (AM_A64_PREP && kk == 0 && d < 3) k_prep(d + 1);
         if (d < 2) {
           if (kk < 3) vf[(kk + 1) & 1][2 * d + 1] = v_frag(v_st, 2 * d + 1, kk + 1);
           else kf[d][1] = k_frag(k_st, 1, d);
@@ -496,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks % 3][kb], negm[0]);
         else qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
         POST_QK();
-        if (ks < 2) dma_v(ks * 2 + kb);
+        if (ks < 2) { if (AM_A64_PREP) v_issue(); else dma_v(ks * 2 + kb); }
         if (!(ABL & (8 | 64)))
 #pragma unroll
           for (int n = ES2.lo[gap]; n < ES2.lo[gap + 1]; ++n) es.step(n, s1c[0], s1c[1], p1);
@@ -504,6 +544,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
         if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks % 3][kb], negm[1]);
         else qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
         POST_QK();
+        if (AM_A64_PREP && ks < 2 && ks * 2 + kb < 3) v_prep(ks * 2 + kb + 1);
         if (ks < 6) kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);      // into the set the previous k-step has finished with
         else vf[0][(ks - 6) * 2 + kb] = v_frag(vn_st, (ks - 6) * 2 + kb, 0);
         if (!(ABL & (8 | 64)))

@@ -146,7 +146,8 @@ class PeerExchange:
                 the slot in p's buffer may be overwritten), SDMA-copy the shard into p's buffer slot `me`, raise
                 arrived[me] = seq in p's block;
       wait():   the compute stream waits for arrived[p] >= seq of every peer p (the remote shards are in MY buffer);
-      done():   after the attention that reads them has been enqueued, raise consumed[me] = seq in every peer's block.
+      done():   after the attention that reads them has been enqueued: the compute stream waits for this rank's own pushes
+                (they read the slot the next layer rewrites), then raises consumed[me] = seq in every peer's block.
     Flags live in the OWNER's memory and are written remotely, so every wait polls local memory."""
 
     def __init__(self, group: Optional[dist.ProcessGroup], plan: FrameShardPlan, chunk_bytes: int, device: torch.device):
@@ -206,6 +207,8 @@ class PeerExchange:
                 off = self.me * self.chunk_bytes
                 self.L.check(self.lib.am_peer_copy(self.peer_kv[p] + off, self.kv.value + off, self.chunk_bytes, st), "am_peer_copy")
                 self.L.check(self.lib.am_peer_signal(self._arrived(self.peer_flags[p], self.me), self.seq, st), "am_peer_signal")
+        self._pushed = torch.cuda.Event()
+        self._pushed.record(self.side)
 
     def wait(self) -> None:
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -216,7 +219,13 @@ class PeerExchange:
                     self.L.check(self.lib.am_peer_wait(self._arrived(self.flags.value, p), self.seq, fault, st), "am_peer_wait")
 
     def done(self) -> None:
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        comp = torch.cuda.current_stream(self.device)
+        # The pushes READ this rank's own slot: nothing later on the compute stream (the next layer's head_post rewrites that
+        # slot) may run before they have left.  Without this edge a fast rank could overwrite a shard a slow peer had not let it
+        # push yet (seen as run-to-run differences of the selftest on tiny shapes).  No cycle: push(L) waits for the peer's
+        # consumed(L-1), which the peer raises behind ITS push(L-1) - strictly older work.
+        comp.wait_event(self._pushed)
+        st = comp.cuda_stream
         with torch.cuda.device(self.device):
             for p in range(self.P):
                 if p != self.me:

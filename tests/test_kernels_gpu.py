@@ -148,7 +148,10 @@ def test_gemm256_pingpong_main_loop(dev, M, N, K, mode):
     if res is not None:
         mag = torch.maximum(mag, res.float().abs())
         ref = ref + res.float()
-    _close(out, ref, ulps=2.0, atol=2e-3 * math.sqrt(K / 64), what=f"gemm256pp {M}x{N}x{K} {mode}", mag=mag)
+    # `ulps` are relative (2^-8 |x|: half to one true bf16 spacing).  GELU mode: the bf16-rounded linear may sit one TRUE ulp from
+    # the rounded fp32 statement (a rounding-boundary case), GELU' ~ 1 carries that to the activation, and the activation's own
+    # rounding can flip once more: two true ulps = up to four relative ones (seen: 1 element in 5e5 at |x| ~ 1.5, error 2^-6).
+    _close(out, ref, ulps=4.0 if mode == "bias_gelu" else 2.0, atol=2e-3 * math.sqrt(K / 64), what=f"gemm256pp {M}x{N}x{K} {mode}", mag=mag)
     # GELU is evaluated on the bf16-rounded linear: a 1-ulp difference of the linear moves the activation by up to 1 ulp of ITS input
     _close(out, old.float(), ulps=2.0 if mode == "bias_gelu" else 1.0, atol=1e-3 * math.sqrt(K / 64),
            what=f"gemm256pp vs lockstep {M}x{N}x{K} {mode}", mag=mag)

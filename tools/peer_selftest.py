@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--tokens", type=int, default=511)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--forwards", type=int, default=3)
+    ap.add_argument("--serial", action="store_true", help="diagnostic: device sync + process barrier inside every exchange "
+                    "(all pushes have landed everywhere before anybody reads): separates protocol races from compute nondeterminism")
+    ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
     from actionmesh_amd.denoiser import HipEngine, masked_time, rope_tables_host
@@ -47,10 +50,20 @@ def main():
     cos, sin = rope_tables_host(f_in, 128)
 
     plan = FrameShardPlan(T, world, rank)                       # frame sharding only: every rank exchanges with every other
-    eng = HipEngine(hp, sd, dev, B, plan.frames_local, N, S, world=world, rank=rank,
+    eng = HipEngine(hp, sd, dev, B, plan.frames_local, N, S, world=world, rank=rank, attn_defer_log2=a.defer,
                     kv_factory=lambda nbytes: PeerExchange(dist.group.WORLD, plan, nbytes, dev))
     eng.set_context(plan.slice_frames(c_in.to(dev)), cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64),
                     sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64))
+    if a.serial:
+        ex = eng.exchange
+        wait0, done0 = ex.wait, ex.done
+
+        def wait_serial():
+            torch.cuda.synchronize(dev); dist.barrier(); wait0(); torch.cuda.synchronize(dev)
+
+        def done_serial():
+            done0(); torch.cuda.synchronize(dev); dist.barrier()
+        ex.wait, ex.done = wait_serial, done_serial
     tl = plan.frames_local
     t_local = [t_bt[b * T + rank * tl + j] for b in range(B) for j in range(tl)]
     outs = []
@@ -59,7 +72,21 @@ def main():
         torch.cuda.synchronize(dev)
         outs.append(v_local.float().cpu())
     assert not eng.exchange.faulted(), "a flag wait gave up"
-    assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
+    if not all(torch.equal(o, outs[0]) for o in outs[1:]):          # diagnostics: which forward, which frames / tokens
+        for k, o in enumerate(outs[1:], 1):
+            d = (o - outs[0]).abs()
+            bad = d > 0
+            print(f"[peer_selftest] rank {rank}: forward {k} vs 0: {int(bad.sum())}/{bad.numel()} differ, max {float(d.max()):.3e}; "
+                  f"per (b, frame) counts {bad.flatten(2).sum(-1).tolist()}; tokens hit {int(bad.any(-1).sum())}", flush=True)
+    if a.same_device:
+        # Ranks SHARING one GPU (this mode only): repeated forwards agree to <= 2 bf16 ulp but not always bit for bit, also with the
+        # exchange fully serialised (--serial), while one process with two engines (tools/twopass_determinism.py) and two
+        # independent processes on one GPU (tools/share_determinism.py) are bitwise repeatable - an open observation about
+        # GPU sharing, not about a shard read early or late (that error is O(1), not an ulp).  DESIGN.md section 9.
+        worst = max(float((o - outs[0]).norm() / outs[0].norm()) for o in outs[1:])
+        assert worst < 2e-3, f"forwards differ by rel-L2 {worst:.3e}: a shard was read before it arrived / after it was overwritten"
+    else:
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
     parts = [torch.empty_like(outs[0]) for _ in range(world)]
     dist.all_gather(parts, outs[0])
     if rank == 0:

@@ -79,12 +79,13 @@ def main():
             print(f"[peer_selftest] rank {rank}: forward {k} vs 0: {int(bad.sum())}/{bad.numel()} differ, max {float(d.max()):.3e}; "
                   f"per (b, frame) counts {bad.flatten(2).sum(-1).tolist()}; tokens hit {int(bad.any(-1).sum())}", flush=True)
     if a.same_device:
-        # Ranks SHARING one GPU (this mode only): repeated forwards agree to <= 2 bf16 ulp but not always bit for bit, also with the
+        # Ranks SHARING one GPU (this mode only): repeated forwards agree to <= 2 bf16 ulp per element (rel-L2 ~2e-3 when half of the
+        # elements move by one ulp) but not always bit for bit, also with the
         # exchange fully serialised (--serial), while one process with two engines (tools/twopass_determinism.py) and two
         # independent processes on one GPU (tools/share_determinism.py) are bitwise repeatable - an open observation about
         # GPU sharing, not about a shard read early or late (that error is O(1), not an ulp).  DESIGN.md section 9.
         worst = max(float((o - outs[0]).norm() / outs[0].norm()) for o in outs[1:])
-        assert worst < 2e-3, f"forwards differ by rel-L2 {worst:.3e}: a shard was read before it arrived / after it was overwritten"
+        assert worst < 5e-3, f"forwards differ by rel-L2 {worst:.3e}: a shard was read before it arrived / after it was overwritten"
     else:
         assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
     parts = [torch.empty_like(outs[0]) for _ in range(world)]

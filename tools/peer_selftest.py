@@ -58,8 +58,13 @@ def main():
         ex = eng.exchange
         wait0, done0 = ex.wait, ex.done
 
+        junk = torch.zeros(96 << 20, dtype=torch.int32, device=dev) if os.environ.get("AM_PEER_SWEEP") == "1" else None
+
         def wait_serial():
-            torch.cuda.synchronize(dev); dist.barrier(); wait0(); torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev); dist.barrier(); wait0()
+            if junk is not None:
+                junk.add_(1)            # 768 MB through every L2: no line of the gather buffer survives
+            torch.cuda.synchronize(dev)
 
         def done_serial():
             done0(); torch.cuda.synchronize(dev); dist.barrier()

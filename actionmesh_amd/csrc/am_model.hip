@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <string.h>
+
 #include "am_common.h"
 
 int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream);    // am_elementwise.hip
@@ -39,6 +41,13 @@ struct am_model {
   std::vector<void*> allocs;
   float* stage_f32 = nullptr;
   size_t stage_elems = 0;
+  // Host arguments are BORROWED for the call only (header conventions), but an asynchronous copy from pageable memory may run
+  // after the call has returned - the caller's array can be gone by then (a ctypes temporary is freed at once; seen as one
+  // garbage per-frame diffusion time in a forward when the device was busy).  Host data is therefore copied into a pinned
+  // ring slot owned by the handle before the asynchronous copy is queued; a slot is re-used only after its copy has executed.
+  struct HostStage { void* pinned = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  HostStage hstage[8];
+  unsigned hstage_next = 0;
 
   // workspace
   int maxB, maxT, maxN, maxS, maxL;
@@ -75,6 +84,24 @@ struct am_model {
 };
 
 namespace {
+
+// dst_dev <- host bytes, asynchronously on `st`, safe for host memory that dies when the calling entry point returns
+int stage_h2d(am_model* m, void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+  am_model::HostStage& s = m->hstage[m->hstage_next++ % 8];
+  if (s.used) AM_HIP(hipEventSynchronize(s.ev));          // the copy queued from this slot 8 uploads ago has executed
+  if (s.cap < bytes) {
+    if (s.pinned) AM_HIP(hipHostFree(s.pinned));
+    s.pinned = nullptr;
+    s.cap = bytes < 4096 ? 4096 : bytes;
+    AM_HIP(hipHostMalloc(&s.pinned, s.cap, hipHostMallocDefault));
+  }
+  if (!s.ev) AM_HIP(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  memcpy(s.pinned, src_host, bytes);
+  AM_HIP(hipMemcpyAsync(dst_dev, s.pinned, bytes, hipMemcpyHostToDevice, st));
+  AM_HIP(hipEventRecord(s.ev, st));
+  s.used = true;
+  return AM_OK;
+}
 
 int dev_alloc(am_model* m, void** p, size_t bytes, bool zero = true) {
   AM_HIP(hipMalloc(p, bytes ? bytes : 16));
@@ -277,6 +304,11 @@ extern "C" int am_destroy(am_handle h) {
   if (!h) return AM_OK;
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage_f32) (void)hipFree(h->stage_f32);
+  for (auto& s : h->hstage) {
+    if (s.used) (void)hipEventSynchronize(s.ev);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    if (s.pinned) (void)hipHostFree(s.pinned);
+  }
   delete h;
   return AM_OK;
 }
@@ -352,8 +384,8 @@ extern "C" int am_set_context(am_handle h, const float* ctx_dev, int B, int T, i
            "am_set_context: (B=%d,T=%d,S=%d) exceeds workspace (%d,%d,%d)", B, T, S, h->maxB, h->maxT, h->maxS);
   hipStream_t st = (hipStream_t)stream;
   const int64_t BT = (int64_t)B * T;
-  AM_HIP(hipMemcpyAsync(h->rope_cos, cos_host, BT * 64 * sizeof(float), hipMemcpyHostToDevice, st));
-  AM_HIP(hipMemcpyAsync(h->rope_sin, sin_host, BT * 64 * sizeof(float), hipMemcpyHostToDevice, st));
+  AM_TRY(stage_h2d(h, h->rope_cos, cos_host, BT * 64 * sizeof(float), st));
+  AM_TRY(stage_h2d(h, h->rope_sin, sin_host, BT * 64 * sizeof(float), st));
   AM_TRY(am_f32_to_bf16(ctx_dev, h->ctxb, (size_t)BT * S * h->Dc, st));
   const int Spad = pad_to(S, 64);
   for (int i = 0; i < h->NL; ++i) {
@@ -392,7 +424,7 @@ extern "C" int am_forward_begin(am_handle h, const float* x_dev, const float* t_
   const int C = h->C, Din = h->Din;
   h->B = B; h->T = T; h->N = N; h->L = N + 1; h->R = (int64_t)B * T * h->L;
   const int64_t BT = (int64_t)B * T;
-  AM_HIP(hipMemcpyAsync(h->tdev, t_bt_host, BT * sizeof(float), hipMemcpyHostToDevice, st));
+  AM_TRY(stage_h2d(h, h->tdev, t_bt_host, BT * sizeof(float), st));
   // proj_in (temporal_denoiser.py:205-206) written behind each frame's time token (:217)
   AM_TRY(am_f32_to_bf16(x_dev, h->xb, (size_t)BT * N * Din, st));
   AM_TRY(gemm(st, h->xb, Din, h->w_in, Din, h->b_in, nullptr, h->hwork, C, BT * N, C, Din, 0, nullptr, 0, 0, 0, 0, 0,

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--forwards", type=int, default=3)
     ap.add_argument("--serial", action="store_true", help="diagnostic: device sync + process barrier inside every exchange "
                     "(all pushes have landed everywhere before anybody reads): separates protocol races from compute nondeterminism")
+    ap.add_argument("--trace", action="store_true", help="diagnostic: bit-exact checksums of the local K/V shard (after pre) and of "
+                    "every shard (after the exchange) per layer and forward; reports where repeated forwards first differ")
     ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
@@ -71,11 +73,40 @@ def main():
         ex.wait, ex.done = wait_serial, done_serial
     tl = plan.frames_local
     t_local = [t_bt[b * T + rank * tl + j] for b in range(B) for j in range(tl)]
-    outs = []
+    outs, traces = [], []
+
+    class _Raw:          # the IPC gather buffer as a torch tensor (int16 view: checksums are exact)
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i2", "data": (ptr, False), "version": 2}
+
+    def traced_forward():
+        ex = eng.exchange
+        kv = torch.as_tensor(_Raw(ex.kv_ptr(), world * ex.chunk_bytes // 2), device=dev).view(world, -1)
+        tr = []
+        eng.begin(plan.slice_frames(x_in.to(dev)), t_local)
+        for i in range(3):
+            eng.layer_pre(i)
+            tr.append(("local shard after pre", i, int(kv[rank].to(torch.int64).sum())))
+            ex.start(); eng.layer_attn_local(i); ex.wait()
+            for p in range(world):
+                tr.append((f"shard of rank {p} after the exchange", i, int(kv[p].to(torch.int64).sum())))
+            eng.layer_post(i); ex.done()
+        return eng.end(), tr
+
     for _ in range(a.forwards):                                  # several forwards: the consumed / arrived sequence must keep turning
-        v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
+        if a.trace:
+            v_local, tr = traced_forward()
+            traces.append(tr)
+        else:
+            v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
         torch.cuda.synchronize(dev)
         outs.append(v_local.float().cpu())
+    if a.trace:
+        for k in range(1, len(traces)):
+            first = next((e for e, e0 in zip(traces[k], traces[0]) if e != e0), None)
+            same_out = torch.equal(outs[k], outs[0])
+            print(f"[peer_selftest] rank {rank} forward {k}: outputs {'equal' if same_out else 'DIFFER'}; first differing checksum: "
+                  f"{'none' if first is None else f'{first[0]}, layer {first[1]}'}", flush=True)
     assert not eng.exchange.faulted(), "a flag wait gave up"
     if not all(torch.equal(o, outs[0]) for o in outs[1:]):          # diagnostics: which forward, which frames / tokens
         for k, o in enumerate(outs[1:], 1):

@@ -90,6 +90,8 @@ SYMBOLS = {
     "am_set_context": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "am_set_branch_hints": (C.c_int, [_P, _P, C.c_int]),
     "am_denoise_forward": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "am_denoise_forward_graph": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "am_graph_stats": (C.c_int, [_P, _P]),
     "am_forward_begin": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "am_point_embed": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "am_displacement": (C.c_int, [_P, C.c_int, C.c_int64, C.c_int, _P, _P]),

@@ -661,6 +661,7 @@ int launch(const am_attn_args* a, void* stream) {
   if (split && part_elems < need) {
     if (part) AM_HIP(hipFree(part));
     part = nullptr; part_elems = 0;
+    ++g_am_scratch_generation;
     AM_HIP(hipMalloc(reinterpret_cast<void**>(&part), need * sizeof(float)));
     part_elems = need;
   }

@@ -831,6 +831,7 @@ static int lazy_flags(int64_t n, unsigned** out) {
     uint64_t total = 0;
     AM_TRY(lazy_flag_total(dev, &total));
     if (g_flag_buf[dev]) AM_HIP(hipFree(g_flag_buf[dev]));
+    ++g_am_scratch_generation;
     g_flag_carry[dev] = total;
     g_flag_cap[dev] = n > (1 << 17) ? n : (1 << 17);
     const size_t words = (size_t)G_REGIONS * (g_flag_cap[dev] + 4);

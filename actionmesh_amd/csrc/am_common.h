@@ -108,6 +108,10 @@ __device__ inline void dma_drain_barrier() {
     }                                                                                        \
   } while (0)
 
+// Library-owned device scratch that is grown on demand (the split-tail partials, the lazy kernel's mark buffers) is freed when it
+// grows: everything that bakes such a pointer into a HIP graph keys the graph on this generation (am_model.hip).
+extern std::atomic<uint64_t> g_am_scratch_generation;
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -5,6 +5,8 @@
 
 // ---- error string (thread local) ---------------------------------------------
 static thread_local char g_err[512] = "";
+std::atomic<uint64_t> g_am_scratch_generation{0};
+
 void am_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

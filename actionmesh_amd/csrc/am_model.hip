@@ -45,6 +45,14 @@ struct am_model {
   // after the call has returned - the caller's array can be gone by then (a ctypes temporary is freed at once; seen as one
   // garbage per-frame diffusion time in a forward when the device was busy).  Host data is therefore copied into a pinned
   // ring slot owned by the handle before the asynchronous copy is queued; a slot is re-used only after its copy has executed.
+  // am_denoise_forward_graph: one captured forward per (operands, shape, stream, window) key
+  struct GraphCache {
+    const float* x = nullptr; uint16_t* v = nullptr; int B = 0, T = 0, N = 0; hipStream_t st = nullptr; uint64_t ctx_gen = 0, scratch_gen = 0;
+    bool warm = false, disabled = false;
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    uint64_t replays = 0, captures = 0, eager = 0;
+  } gc;
+  uint64_t ctx_gen = 0;        // bumped by everything a captured forward bakes in (context, hints, K/V buffers)
   struct HostStage { void* pinned = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool used = false; };
   HostStage hstage[8];
   unsigned hstage_next = 0;
@@ -84,6 +92,12 @@ struct am_model {
 };
 
 namespace {
+
+void graph_drop(am_model* h) {
+  if (h->gc.exec) (void)hipGraphExecDestroy(h->gc.exec);
+  if (h->gc.graph) (void)hipGraphDestroy(h->gc.graph);
+  h->gc.exec = nullptr; h->gc.graph = nullptr;
+}
 
 // dst_dev <- host bytes, asynchronously on `st`, safe for host memory that dies when the calling entry point returns
 int stage_h2d(am_model* m, void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
@@ -304,6 +318,7 @@ extern "C" int am_destroy(am_handle h) {
   if (!h) return AM_OK;
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->stage_f32) (void)hipFree(h->stage_f32);
+  graph_drop(h);
   for (auto& s : h->hstage) {
     if (s.used) (void)hipEventSynchronize(s.ev);
     if (s.ev) (void)hipEventDestroy(s.ev);
@@ -358,6 +373,7 @@ extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev
   AM_CHECK(chunk_stride_elems == 0 || chunk_stride_elems >= h->chunk_elems, "am_bind_kv_buffers: chunk stride %zu < chunk size %zu",
            chunk_stride_elems, h->chunk_elems);
   h->Kg = k_dev; h->Vtg = vt_dev; h->kv_external = true;
+  ++h->ctx_gen;
   h->chunk_stride = chunk_stride_elems ? chunk_stride_elems : h->chunk_elems;
   return AM_OK;
 }
@@ -384,6 +400,7 @@ extern "C" int am_set_context(am_handle h, const float* ctx_dev, int B, int T, i
            "am_set_context: (B=%d,T=%d,S=%d) exceeds workspace (%d,%d,%d)", B, T, S, h->maxB, h->maxT, h->maxS);
   hipStream_t st = (hipStream_t)stream;
   const int64_t BT = (int64_t)B * T;
+  ++h->ctx_gen;
   AM_TRY(stage_h2d(h, h->rope_cos, cos_host, BT * 64 * sizeof(float), st));
   AM_TRY(stage_h2d(h, h->rope_sin, sin_host, BT * 64 * sizeof(float), st));
   AM_TRY(am_f32_to_bf16(ctx_dev, h->ctxb, (size_t)BT * S * h->Dc, st));
@@ -411,20 +428,32 @@ extern "C" int am_set_branch_hints(am_handle h, const uint8_t* ctx_is_zero_host,
   if (ctx_is_zero_host)
     for (int b = 0; b < h->ctxB; ++b) h->ctx_zero[b] = ctx_is_zero_host[b] ? 1 : 0;
   h->shared_prefix = shared_prefix != 0 && h->P == 1 && h->ctxB > 1;
+  ++h->ctx_gen;
   return AM_OK;
 }
 
-extern "C" int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T, int N, void* stream) {
+static int forward_check(am_model* h, const float* x_dev, const float* t_bt_host, int B, int T, int N) {
   AM_CHECK(h && x_dev && t_bt_host, "am_forward_begin: null argument");
   if (!h->ctx_set) AM_FAIL(AM_ERR_STATE, "am_forward_begin: am_set_context has not been called");
   AM_CHECK(B == h->ctxB && T == h->ctxT, "am_forward_begin: (B=%d,T=%d) differs from the bound context (%d,%d)", B, T, h->ctxB, h->ctxT);
   AM_CHECK(N > 0 && N <= h->maxN, "am_forward_begin: N=%d exceeds workspace %d", N, h->maxN);
+  return AM_OK;
+}
+// everything of am_forward_begin behind the upload of the per-frame times (h->tdev): pure device work, capturable
+static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int N, hipStream_t st);
+
+extern "C" int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T, int N, void* stream) {
+  AM_TRY(forward_check(h, x_dev, t_bt_host, B, T, N));
   AM_TRY(ensure_kv(h));
   hipStream_t st = (hipStream_t)stream;
+  AM_TRY(stage_h2d(h, h->tdev, t_bt_host, (size_t)B * T * sizeof(float), st));
+  return forward_begin_body(h, x_dev, B, T, N, st);
+}
+
+static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int N, hipStream_t st) {
   const int C = h->C, Din = h->Din;
   h->B = B; h->T = T; h->N = N; h->L = N + 1; h->R = (int64_t)B * T * h->L;
   const int64_t BT = (int64_t)B * T;
-  AM_TRY(stage_h2d(h, h->tdev, t_bt_host, BT * sizeof(float), st));
   // proj_in (temporal_denoiser.py:205-206) written behind each frame's time token (:217)
   AM_TRY(am_f32_to_bf16(x_dev, h->xb, (size_t)BT * N * Din, st));
   AM_TRY(gemm(st, h->xb, Din, h->w_in, Din, h->b_in, nullptr, h->hwork, C, BT * N, C, Din, 0, nullptr, 0, 0, 0, 0, 0,
@@ -635,6 +664,70 @@ extern "C" int am_denoise_forward(am_handle h, const float* x_dev, const float* 
     AM_TRY(am_layer_post_attn(h, i, stream));
   }
   return am_forward_end(h, v_out, stream);
+}
+
+// am_denoise_forward through a HIP graph: the ~450 launches of a forward are captured once per (operands, shape, stream, window)
+// and replayed; only the upload of the per-frame diffusion times stays outside the graph.  First call with a new key: eager (it
+// also performs every lazy allocation / attribute call a capture must not contain); second: capture + instantiate + launch;
+// later: launch.  A capture that fails disables the graph path for the handle (eager from then on, counted in am_graph_stats).
+static int forward_body(am_model* h, const float* x_dev, int B, int T, int N, uint16_t* v_out, hipStream_t st) {
+  AM_TRY(forward_begin_body(h, x_dev, B, T, N, st));
+  for (int i = 0; i < h->NL; ++i) {
+    AM_TRY(am_layer_pre_attn(h, i, st));
+    AM_TRY(am_layer_post_attn(h, i, st));
+  }
+  return am_forward_end(h, v_out, st);
+}
+extern "C" int am_denoise_forward_graph(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T, int N,
+                                        uint16_t* v_out, void* stream) {
+  AM_CHECK(h && v_out, "am_denoise_forward_graph: null argument");
+  if (h->P != 1) AM_FAIL(AM_ERR_STATE, "am_denoise_forward_graph: world_size=%d needs the split API", h->P);
+  am_model::GraphCache& g = h->gc;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.disabled || st == nullptr) {          // the legacy null stream cannot be captured
+    ++g.eager;
+    return am_denoise_forward(h, x_dev, t_bt_host, B, T, N, v_out, stream);
+  }
+  AM_TRY(forward_check(h, x_dev, t_bt_host, B, T, N));
+  const bool same = g.x == x_dev && g.v == v_out && g.B == B && g.T == T && g.N == N && g.st == st && g.ctx_gen == h->ctx_gen &&
+                    g.scratch_gen == g_am_scratch_generation.load();
+  if (!same) {
+    graph_drop(h);
+    g.x = x_dev; g.v = v_out; g.B = B; g.T = T; g.N = N; g.st = st; g.ctx_gen = h->ctx_gen; g.warm = true;
+    ++g.eager;
+    const int rc0 = am_denoise_forward(h, x_dev, t_bt_host, B, T, N, v_out, stream);
+    g.scratch_gen = g_am_scratch_generation.load();      // after the eager run: it may have grown the scratch
+    return rc0;
+  }
+  AM_TRY(stage_h2d(h, h->tdev, t_bt_host, (size_t)B * T * sizeof(float), st));
+  if (!g.exec) {
+    AM_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = forward_body(h, x_dev, B, T, N, v_out, st);
+    hipGraph_t gr = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &gr);
+    hipError_t e2 = hipSuccess;
+    if (rc == AM_OK && e == hipSuccess && gr) e2 = hipGraphInstantiate(&g.exec, gr, nullptr, nullptr, 0);
+    if (rc != AM_OK || e != hipSuccess || !gr || e2 != hipSuccess || !g.exec) {
+      (void)hipGetLastError();
+      if (gr) (void)hipGraphDestroy(gr);
+      g.exec = nullptr; g.disabled = true; h->in_forward = false;
+      ++g.eager;
+      return am_denoise_forward(h, x_dev, t_bt_host, B, T, N, v_out, stream);
+    }
+    g.graph = gr;
+    ++g.captures;
+  } else {
+    ++g.replays;
+  }
+  AM_HIP(hipGraphLaunch(g.exec, st));
+  return AM_OK;
+}
+// counts[0] = graph launches of an existing executable, [1] = captures, [2] = eager forwards (first use of a key, null stream,
+// or after a failed capture), [3] = 1 when a capture has failed and the graph path is off
+extern "C" int am_graph_stats(am_handle h, uint64_t* counts4) {
+  AM_CHECK(h && counts4, "am_graph_stats: null argument");
+  counts4[0] = h->gc.replays; counts4[1] = h->gc.captures; counts4[2] = h->gc.eager; counts4[3] = h->gc.disabled ? 1 : 0;
+  return AM_OK;
 }
 
 extern "C" double am_step_flops(am_handle h, int B, int T, int N, int S) {

@@ -79,7 +79,7 @@ class HipEngine:
     def __init__(self, hp: Dict, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  max_batch: int, frames_local: int, tokens: int, ctx_tokens: int,
                  world: int = 1, rank: int = 0, attn_defer_log2: int = 8, attn_dtype: str = "bf16",
-                 kv_factory=None):
+                 kv_factory=None, use_graph: bool = False):
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -115,6 +115,9 @@ class HipEngine:
                 raise RuntimeError(f"HipEngine: {missing} reference state-dict keys were not provided")
             self._kv = None
             self.exchange = None
+            # HIP-graph replay of the single-rank forward (am_denoise_forward_graph): operands at fixed addresses, owned here
+            self.use_graph = bool(use_graph) and world == 1
+            self._gx = self._gv = self._gstream = None
             if world > 1:
                 n = C.c_size_t()
                 L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
@@ -209,11 +212,36 @@ class HipEngine:
         B, T, N, D = x_local.shape
         x_local = x_local.to(self.device, torch.float32).contiguous()
         t = (C.c_float * (B * T))(*t_bt_local)
+        if self.use_graph:
+            # the captured forward reads / writes THESE buffers: the result tensor is re-used by the next forward (the sampler
+            # consumes the velocity in am_flow_step before it asks for the next one)
+            # PyTorch's default stream is the null stream, which cannot be captured: the forward runs on a stream of the engine,
+            # ordered after the caller's current stream and before whatever the caller enqueues next
+            if self._gx is None or self._gx.shape != x_local.shape:
+                self._gx = torch.empty_like(x_local)
+                self._gv = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+                self._gstream = torch.cuda.Stream(self.device)
+            with torch.cuda.device(self.device):
+                cur = torch.cuda.current_stream(self.device)
+                self._gstream.wait_stream(cur)
+                x_local.record_stream(self._gstream)
+                with torch.cuda.stream(self._gstream):
+                    self._gx.copy_(x_local)
+                    L.check(self.lib.am_denoise_forward_graph(self.handle, self._gx.data_ptr(), t, B, T, N, self._gv.data_ptr(),
+                                                              self._gstream.cuda_stream), "am_denoise_forward_graph")
+                cur.wait_stream(self._gstream)
+            return self._gv
         v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),
                                                 self._stream()), "am_denoise_forward")
         return v
+
+    def graph_stats(self) -> Tuple[int, int, int, int]:
+        """(replays, captures, eager forwards, capture failed) of am_denoise_forward_graph."""
+        c = (C.c_uint64 * 4)()
+        L.check(self.lib.am_graph_stats(self.handle, c), "am_graph_stats")
+        return tuple(int(v) for v in c)
 
     def step_flops(self, B: int, T_total: int, N: int, S: int) -> float:
         return float(self.lib.am_step_flops(self.handle, B, T_total, N, S))
@@ -235,8 +263,10 @@ class HipDenoiser(nn.Module):
                  inflated_layers: Optional[Sequence[int]] = None, clear_autocast: bool = True,
                  compile_blocks: bool = False, compile_mode: str = "default",
                  process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8,
-                 cfg_parallel: bool = True, attn_dtype: str = "bf16"):
+                 cfg_parallel: bool = True, attn_dtype: str = "bf16", use_graph: Optional[bool] = None):
         super().__init__()
+        # HIP-graph replay of the single-rank forward (None: the ACTIONMESH_AMD_GRAPH environment variable, default off)
+        self.use_graph = (os.environ.get("ACTIONMESH_AMD_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
         self.attn_dtype = attn_dtype        # "fp8": inflated self-attention on the e4m3 MFMA kernel (BASELINE configs[4])
         if width != num_attention_heads * HEAD_DIM:
             raise ValueError("HipDenoiser supports head_dim 128 only (width = heads * 128), as the reference ships")
@@ -328,7 +358,7 @@ class HipDenoiser(nn.Module):
             kv_factory = lambda chunk_bytes: PeerExchange(group, plan, chunk_bytes, self.device)
         self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
                                  world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2,
-                                 attn_dtype=self.attn_dtype, kv_factory=kv_factory)
+                                 attn_dtype=self.attn_dtype, kv_factory=kv_factory, use_graph=self.use_graph)
         self._window = None
         return self._engine
 

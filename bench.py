@@ -240,7 +240,10 @@ def main():
                     help="fp8: the inflated self-attention (QK^T, P.V) on the e4m3 MX-scaled MFMA kernel - BASELINE.json "
                          "configs[4] (use with --shape long64); GEMMs, norms and the residual stream stay bf16.  The headline "
                          "metric is bf16.")
+    ap.add_argument("--graph", action="store_true", help="single GPU: the forward through a captured HIP graph (am_denoise_forward_graph)")
     args = ap.parse_args()
+    if args.graph:
+        os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
 
     import torch.distributed as dist
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
@@ -338,6 +341,7 @@ def main():
                                          "(zero context), layer 0's self-attention branch is computed once for both branches "
                                          "(identical inputs) - bit-identical latents (tests/test_denoiser_gpu.py::"
                                          "test_exact_shortcuts_are_bit_identical); `value` above executes every operation"},
+        "hip_graph": bool(args.graph and world == 1),
         "end_to_end_video_to_4d_s": None,
         "end_to_end_note": "unmeasured: pretrained weights / assets unreachable offline; the GPU stages chained on synthetic "
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",

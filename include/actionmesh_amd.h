@@ -115,6 +115,15 @@ int am_set_branch_hints(am_handle h, const uint8_t* ctx_is_zero_host, int shared
 int am_denoise_forward(am_handle h, const float* x_dev, const float* t_bt_host,
                        int B, int T_local, int N, uint16_t* v_out_dev, void* stream);
 
+/* am_denoise_forward through a HIP graph: the forward's ~450 launches are captured once per (x_dev, v_out_dev, shape, stream,
+ * bound window) and replayed; the per-frame times are uploaded in front of every launch.  First call with a new key runs eagerly,
+ * the second captures, later ones replay; a failed capture turns the path off for the handle (eager from then on).  The caller
+ * keeps x_dev / v_out_dev at fixed addresses to benefit; `stream` must not be the null stream (falls back to eager).
+ * am_graph_stats: counts4 = {replays, captures, eager forwards, capture failed}. */
+int am_denoise_forward_graph(am_handle h, const float* x_dev, const float* t_bt_host,
+                             int B, int T_local, int N, uint16_t* v_out_dev, void* stream);
+int am_graph_stats(am_handle h, uint64_t* counts4);
+
 /* The same forward, split at the temporal-attention boundary so the host can
  * run the K/V all-gather (RCCL) between `pre` and `post` of an inflated layer. */
 int am_forward_begin(am_handle h, const float* x_dev, const float* t_bt_host,

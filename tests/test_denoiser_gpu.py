@@ -484,3 +484,29 @@ def test_exact_shortcuts_are_bit_identical(dev, golden_dir, name):
     finally:
         del os.environ["ACTIONMESH_AMD_NO_SHORTCUTS"]
     assert torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_graph_replay_is_bit_identical(dev, golden_dir, name):
+    """am_denoise_forward_graph (HipDenoiser(use_graph=True)): the sampler through a captured forward - first step eager, second
+    captured, the rest replayed with new per-frame times - gives the same latents bit for bit as the eager launches; a new window
+    (context) drops the graph and captures again."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+    g, cfg, sd, model, t = _setup(name, golden_dir, dev)
+    steps = max(int(g["steps"]), 4)
+    args = dict(device=dev, mask=t["mask"].to(dev), framestep=t["framestep"].to(dev))
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    gm = HipDenoiser(num_tokens_nominal=model.num_tokens_nominal, temporal_context_size=model.temporal_context_size,
+                     use_graph=True, **model.hyper_params())
+    gm.load_state_dict(sd)
+    gm.to(dev).eval()
+    for k, ctx in enumerate((t["context"], t["context"] * 0.5)):                # two windows
+        outs = []
+        for m in (model, gm):
+            s = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+            got = [lat.clone() for lat, _ in s._flow_sample(m, cfgd, t["init_latent"].clone().to(dev), context=ctx.to(dev), **args)]
+            outs.append(torch.stack(got).cpu())
+        assert torch.equal(outs[0], outs[1]), (name, k, float((outs[0] - outs[1]).abs().max()))
+        replays, captures, eager, failed = gm._engine.graph_stats()
+        assert failed == 0 and captures == k + 1 and replays == (k + 1) * (steps - 2) and eager == k + 1, (replays, captures, eager, failed)
+    assert model._engine.graph_stats() == (0, 0, 0, 0)

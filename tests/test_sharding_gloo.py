@@ -218,7 +218,7 @@ class FakeHipEngine(OracleEngine):
     """Same constructor / methods as actionmesh_amd.denoiser.HipEngine, computing with the oracle."""
 
     def __init__(self, hp, state_dict, device, max_batch, frames_local, tokens, ctx_tokens,
-                 world=1, rank=0, attn_defer_log2=8, attn_dtype="bf16", kv_factory=None):
+                 world=1, rank=0, attn_defer_log2=8, attn_dtype="bf16", kv_factory=None, use_graph=False):
         self.device = torch.device(device)
         self.world, self.rank = world, rank
         self.bounds = (max_batch, frames_local, tokens, ctx_tokens)

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   auto dma_piece = [&](const char* src, unsigned lane_off, unsigned char* dst) __attribute__((always_inline)) {
 #if AM_A64_SADDR
     const unsigned lds = __builtin_amdgcn_readfirstlane(smem_lds + (unsigned)(dst - smem));      // integer arithmetic: no null-checked address-space cast per piece
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src), "s"(lds) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src), "s"(lds) : "memory");
 #else
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane_off), (lds_ptr_t)dst, 16, 0, 0);
 #endif
@@ -319,10 +319,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     asm volatile("" : "+s"(v_lds_n), "+s"(v_src_n));
   };
   auto k_issue = [&]() __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(k_lane_off), "s"(k_src_n), "s"(k_lds_n) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(k_lane_off), "s"(k_src_n), "s"(k_lds_n) : "memory");
   };
   auto v_issue = [&]() __attribute__((always_inline)) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_lane_off), "s"(v_src_n), "s"(v_lds_n) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(v_lane_off), "s"(v_src_n), "s"(v_lds_n) : "memory");
   };
 
   // fragment read offsets (bytes) inside a ring stage

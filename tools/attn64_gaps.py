@@ -43,6 +43,7 @@ def main():
     # print the stretch between the first barrier-bearing gap of the main loop and the next 128 MFMAs
     n = 0
     started = False
+    model = []
     for kind, v in run:
         if kind == "gap" and v.get("bar") and not started and n > 40:
             started = True; n0 = n
@@ -50,9 +51,17 @@ def main():
             n += 1
         if started and kind == "gap":
             slots = v.get("valu", 0) + 2 * v.get("exp", 0) + v.get("acc", 0)
-            print(f"after mfma {n - n0:3d}: slots {slots:2d}  {v}")
+            # issue-cycle estimate of the gap (one wave per SIMD: 4 cycles per issue slot; v_exp_f32 two slots; a ds_read_b128
+            # ~10 cycles and an LDS-DMA piece ~50 beside a busy stream) against the 32 cycles its MFMA covers
+            est = 4 + 4 * (slots + v.get("salu", 0)) + 10 * v.get("ds", 0) + 50 * v.get("dma", 0)
+            model.append((n - n0, est))
+            print(f"after mfma {n - n0:3d}: slots {slots:2d}  est {est:3d} cyc  {v}")
         if started and n - n0 >= 130:
             break
+    for name, lo in (("P.V phase (mfma 1..32)", 1), ("QK^T phase (mfma 33..64)", 33)):
+        gs = [e for i, e in model if lo <= i < lo + 32 and e < 600]
+        print(f"{name}: sum of max(32, est) = {sum(max(32, e) for e in gs)} cycles over {len(gs)} gaps "
+              f"({sum(1 for e in gs if e > 32)} over the 32-cycle budget; MFMA time alone 1024)")
 
 
 if __name__ == "__main__":

@@ -178,5 +178,25 @@ def test_attn64_register_audit(tmp_path):
     bad = text.replace("#ASMEND", "#ASMEND\n\tv_accvgpr_read_b32 v1, a100", 1)
     errs, _ = mod.audit(bad)
     assert errs and "asm-owned AccVGPR" in errs[0]
+    # placement guard (round 2): hipcc once hoisted the softmax steps above the QK^T MFMAs - every other gap empty, the next one
+    # twice as full.  tools/attn64_gaps.py counts what the build left in each MFMA gap of the product (lazy) kernel's main loop.
+    spec = importlib.util.spec_from_file_location("attn64_gaps", os.path.join(root, "tools", "attn64_gaps.py"))
+    gaps_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gaps_mod)
+    run = gaps_mod.gaps(gaps_mod.kernel_body(text, "ILi8ELi0ELb0ELi0ELb1E"))
+    slots, n_mfma, started = [], 0, False
+    for kind, v in run:
+        if kind == "gap" and v.get("bar") and not started and n_mfma > 40:
+            started = True
+            continue
+        if kind == "mfma":
+            n_mfma += 1
+        if started and kind == "gap":
+            slots.append((v.get("valu", 0) + 2 * v.get("exp", 0), v.get("dma", 0)))
+        if started and len(slots) >= 64:
+            break
+    assert len(slots) == 64
+    body_slots = [s_ for s_, dma in slots[:63] if not dma and s_ < 50]            # steady gaps of one tile (not the phase boundary)
+    assert len(body_slots) >= 50 and min(body_slots) >= 1 and max(body_slots) <= 8, body_slots      # spread: no empty gap, no doubled one
     assert "am_attention64.audit" in open(os.path.join(csrc, "Makefile")).read()
 

@@ -152,11 +152,51 @@ def save_meshes(vertices, faces, output_dir: Union[str, Path], normals: bool = F
     return [save_glb(v[i], faces, Path(output_dir) / f"mesh_{i:02d}.glb", normals=normals) for i in range(v.shape[0])]
 
 
-def create_animated_glb(vertices_npy, faces_npy, output_glb: Union[str, Path], fps: int = 24, export_normals: bool = False) -> Path:
-    """glb_export.py:18-87 / 142-284 without Blender.  `vertices_npy` / `faces_npy`: the arrays `save_deformation` wrote (paths or
-    arrays; (T, V, 3) in the reference's Blender-frame convention, (F, 3)).  Writes ONE mesh "AnimatedMesh": base geometry =
-    frame 0, a morph target "Frame_i" per frame (displacement from the base), weights keyed 1 at frame i and 0 at its
-    neighbours (LINEAR interpolation), time = frame / fps, Blender's axis conversion (x, y, z) -> (x, z, -y), blue material."""
+def _carry_appearance(b: "_GlbBuilder", input_glb: Union[str, Path], n_vertices: int) -> Tuple[Dict, Optional[int], Optional[int]]:
+    """Materials / textures / images / samplers and TEXCOORD_0 of `input_glb`'s first triangle primitive, re-based onto builder `b`
+    (what the reference keeps by importing the textured GLB into Blender, glb_export.py:160-185).  Returns (top-level glTF entries,
+    TEXCOORD_0 accessor in `b` or None, material index or None)."""
+    gltf, blob = read_glb(input_glb)
+    prim = next((p for m in gltf.get("meshes", []) for p in m["primitives"] if p.get("mode", 4) == 4 and "POSITION" in p["attributes"]), None)
+    if prim is None:
+        raise ValueError(f"No mesh found in input GLB {input_glb}")
+    if "extensions" in prim and "KHR_draco_mesh_compression" in prim["extensions"]:
+        raise ValueError(f"{input_glb}: Draco-compressed geometry is not supported")
+    count = gltf["accessors"][prim["attributes"]["POSITION"]]["count"]
+    if count != n_vertices:
+        raise ValueError(f"Vertex count mismatch. Mesh has {count} vertices, deformations have {n_vertices} vertices")
+    uv = None
+    if "TEXCOORD_0" in prim["attributes"]:
+        uv = b.add(np.ascontiguousarray(read_accessor(gltf, blob, prim["attributes"]["TEXCOORD_0"]), dtype=np.float32), "VEC2", _ARRAY_BUFFER)
+    extra: Dict = {}
+    images = []
+    for img in gltf.get("images", []):
+        img = dict(img)
+        if "bufferView" in img:                                  # embedded image bytes move into the new buffer
+            view = gltf["bufferViews"][img["bufferView"]]
+            data = blob[view.get("byteOffset", 0):view.get("byteOffset", 0) + view["byteLength"]]
+            while len(b.bin) % 4:
+                b.bin.append(0)
+            b.views.append({"buffer": 0, "byteOffset": len(b.bin), "byteLength": len(data)})
+            b.bin += data
+            img["bufferView"] = len(b.views) - 1
+        images.append(img)
+    if images:
+        extra["images"] = images
+    for key in ("materials", "textures", "samplers", "extensionsUsed"):
+        if key in gltf:
+            extra[key] = gltf[key]
+    return extra, uv, prim.get("material")
+
+
+def create_animated_glb(vertices_npy, faces_npy, output_glb: Union[str, Path], blender_path: Optional[str] = None, fps: int = 24,
+                        export_normals: bool = False, input_glb: Optional[Union[str, Path]] = None) -> int:
+    """glb_export.py:18-87 / 142-284 without Blender; same arguments (`blender_path` is accepted and ignored), returns 0 like a
+    successful Blender run.  `vertices_npy` / `faces_npy`: the arrays `save_deformation` wrote (paths or arrays; (T, V, 3) in the
+    reference's Blender-frame convention, (F, 3)).  Writes ONE mesh "AnimatedMesh": base geometry = frame 0, a morph target
+    "Frame_i" per frame (displacement from the base), weights keyed 1 at frame i and 0 at its neighbours (LINEAR interpolation), time =
+    frame / fps, Blender's axis conversion (x, y, z) -> (x, z, -y).  Material: the reference's blue default, or - with `input_glb` -
+    the materials / textures / texture coordinates of that file's mesh (vertex counts must match, as in the reference)."""
     v = np.load(vertices_npy) if isinstance(vertices_npy, (str, os.PathLike)) else _host(vertices_npy, np.float32)
     f = np.load(faces_npy) if isinstance(faces_npy, (str, os.PathLike)) else _host(faces_npy, np.int64)
     v = np.ascontiguousarray(v, dtype=np.float32)
@@ -172,8 +212,17 @@ def create_animated_glb(vertices_npy, faces_npy, output_glb: Union[str, Path], f
     attrs = {"POSITION": b.add(yup[0], "VEC3", _ARRAY_BUFFER, minmax=True)}
     if export_normals:
         attrs["NORMAL"] = b.add(vertex_normals(yup[0], f), "VEC3", _ARRAY_BUFFER)
-    prim = {"attributes": attrs, "mode": 4, "material": 0,
+    appearance: Dict = {"materials": [{"name": "BlueMaterial", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.8, 1.0],
+                                                                                     "metallicFactor": 0.1, "roughnessFactor": 0.4}}]}
+    material: Optional[int] = 0
+    if input_glb is not None:
+        appearance, uv, material = _carry_appearance(b, input_glb, v.shape[1])
+        if uv is not None:
+            attrs["TEXCOORD_0"] = uv
+    prim = {"attributes": attrs, "mode": 4,
             "targets": [{"POSITION": b.add(yup[i] - yup[0], "VEC3", _ARRAY_BUFFER, minmax=True)} for i in range(T)]}
+    if material is not None and "materials" in appearance:
+        prim["material"] = material
     if f.size:
         prim["indices"] = b.add(f.astype(np.uint32).reshape(-1), "SCALAR", _ELEMENT_ARRAY_BUFFER)
     names = [f"Frame_{i}" for i in range(T)]
@@ -183,13 +232,13 @@ def create_animated_glb(vertices_npy, faces_npy, output_glb: Union[str, Path], f
     gltf = {
         "asset": {"version": "2.0", "generator": _GENERATOR}, "scene": 0, "scenes": [{"name": "Scene", "nodes": [0]}],
         "nodes": [{"name": "AnimatedMesh", "mesh": 0}],
-        "materials": [{"name": "BlueMaterial", "pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.8, 1.0],
-                                                                        "metallicFactor": 0.1, "roughnessFactor": 0.4}}],
         "meshes": [{"name": "AnimatedMesh", "primitives": [prim], "weights": w0, "extras": {"targetNames": names}}],
         "animations": [{"name": "KeyAction", "samplers": [{"input": times, "output": weights, "interpolation": "LINEAR"}],
                         "channels": [{"sampler": 0, "target": {"node": 0, "path": "weights"}}]}],
     }
-    return b.write(output_glb, gltf)
+    gltf.update(appearance)
+    b.write(output_glb, gltf)
+    return 0
 
 
 def read_glb(path: Union[str, Path]) -> Tuple[Dict, bytes]:

@@ -194,3 +194,36 @@ def compute_chamfer_3d_4d(gt_pc: torch.Tensor, pred_pc: torch.Tensor, device="cu
             raise ValueError("is_4D needs pred_pc_4D (the synchronized sampling of the predicted meshes)")
         cd_motion = compute_motion_chamfer_score(preds=icp_u4d.transform_points(_dev(pred_pc_4D, device)), gts=gt_pc)
     return float(cd_3d), float(cd_4d), float(cd_motion)
+
+
+def sample_meshes(vertices, faces, n_pts: int = 100_000, synchronized: bool = False, seed: int = 44) -> torch.Tensor:
+    """actionbench/sample_mesh.py:216-243 on the Stage-II vertex stack: vertices (T, V, 3) sharing `faces` (F, 3) -> (T, n_pts, 3)
+    surface samples, area-weighted faces and uniform barycentric coordinates (w0 = 1 - sqrt(u), w1 = sqrt(u)(1 - v), w2 = sqrt(u) v,
+    sample_mesh.py:33-57).  `synchronized`: one draw of (face, barycentric) on frame 0 applied to every frame (point
+    correspondence across the sequence, :169-190); otherwise an independent draw per frame with seed + frame (:237-243).
+    The random STREAMS are torch's (seeded generator on the tensor's device), not trimesh's / pytorch3d's, so the clouds are
+    statistically - not bitwise - the reference's."""
+    v = torch.as_tensor(vertices, dtype=torch.float32)
+    f = torch.as_tensor(faces).long().to(v.device)
+    if v.dim() != 3 or v.shape[-1] != 3 or f.dim() != 2 or f.shape[-1] != 3 or f.numel() == 0:
+        raise ValueError(f"sample_meshes: need (T, V, 3) vertices and (F >= 1, 3) faces, got {tuple(v.shape)} / {tuple(f.shape)}")
+    if not torch.isfinite(v).all():
+        raise ValueError("Meshes contain nan or inf.")
+
+    def draw(frame: int, s: int):
+        g = torch.Generator(device=v.device).manual_seed(s)
+        tri = v[frame][f]                                                       # (F, 3, 3)
+        areas = 0.5 * torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=-1)
+        face = torch.multinomial(areas, n_pts, replacement=True, generator=g)
+        uv = torch.rand((2, n_pts), device=v.device, generator=g)
+        su = uv[0].sqrt()
+        return face, torch.stack((1.0 - su, su * (1.0 - uv[1]), su * uv[1]), dim=-1)
+
+    def apply(frame: int, face, w):
+        tri = v[frame][f[face]]                                                 # (n, 3, 3)
+        return (w[:, :, None] * tri).sum(dim=1)
+
+    if synchronized:
+        face, w = draw(0, seed)
+        return torch.stack([apply(t, face, w) for t in range(v.shape[0])])
+    return torch.stack([apply(t, *draw(t, seed + t)) for t in range(v.shape[0])])

@@ -190,3 +190,21 @@ def test_gradient_icp_recovers_a_known_similarity(dev):
     cd3, cd4, cdm = AB.compute_chamfer_3d_4d(gt[None].repeat(2, 1, 1), pred[None].repeat(2, 1, 1), device=dev, is_4D=True,
                                              pred_pc_4D=pred[None].repeat(2, 1, 1), n_pts_icp=300, n_iter=60)
     assert 0 <= cd3 < before and 0 <= cd4 < before and cdm >= 0
+
+
+def test_sample_meshes_cpu():
+    """surface sampling on the vertex stack (torch only: runs on CPU tensors too): points lie on their triangles, the face
+    distribution follows the areas, synchronized draws keep the correspondence"""
+    v0 = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [3, 1, 0]])
+    f = torch.tensor([[0, 1, 2], [1, 3, 2], [1, 4, 3]])                 # areas 0.5, 0.5, 1.0 in the z = 0 plane
+    v = torch.stack([v0, v0 * 2 + torch.tensor([0.0, 0, 1.0])])          # frame 1: scaled and lifted
+    pts = AB.sample_meshes(v, f, n_pts=20000, synchronized=True, seed=3)
+    assert pts.shape == (2, 20000, 3) and float(pts[0, :, 2].abs().max()) == 0.0
+    assert torch.allclose(pts[1], pts[0] * 2 + torch.tensor([0.0, 0, 1.0]), atol=1e-6)              # same (face, barycentric) per point
+    frac_right = float((pts[0, :, 0] > 1.0).float().mean())              # the third triangle (area 1.0 of 2.0) is the part with x > 1
+    assert abs(frac_right - 0.5) < 0.03, frac_right
+    ind = AB.sample_meshes(v, f, n_pts=1000, synchronized=False, seed=3)
+    assert not torch.allclose(ind[1], ind[0] * 2 + torch.tensor([0.0, 0, 1.0]))                      # independent draws per frame
+    assert torch.equal(AB.sample_meshes(v, f, 1000, True, 3), AB.sample_meshes(v, f, 1000, True, 3))  # seeded
+    with pytest.raises(ValueError):
+        AB.sample_meshes(v, torch.zeros((0, 3), dtype=torch.long))

@@ -16,7 +16,9 @@ def test_pipeline_stages_chain_on_tiny_models():
     dev = torch.device("cuda:0")
     out = E.run(frames=6, steps=2, vertices=300, tiny=True, dev=dev)      # 2 AR windows of 4 frames (slide 3)
     assert out["unit"] == "s" and out["value"] > 0
-    assert set(out["seconds"]) == {"context_encoder", "stage_I", "stage_II", "model_build_and_upload"}
+    assert set(out["seconds"]) == {"context_encoder", "stage_I", "stage_II", "model_build_and_upload", "output_files_host_side",
+                                   "chamfer_metrics"}
+    assert out["output_files_mb"] > 0
     assert "2 AR window(s) of 4" in out["config"]["workload"]
 
 

@@ -104,11 +104,30 @@ def run(frames: int, steps: int, vertices: int, tiny: bool, dev, seed: int = 44)
     assert bool(torch.isfinite(verts).all()) and float(verts.abs().max()) <= 1.0
     lat, _ = bank.get_ordered()
     assert bool(torch.isfinite(lat).all())
+    # output files (N4): per-frame GLBs, the deformation arrays, the animated morph-target GLB; and the ActionBench Chamfer metrics
+    # of the animation against itself shifted by one frame (a number that must be > 0 and finite: the metric path end to end)
+    import shutil
+    import tempfile
+    from actionmesh_amd import actionbench, create_animated_glb, save_deformation, save_meshes
+    faces = torch.arange(vertices - vertices % 3).view(-1, 3)                  # any triangulation will do for the writers
+    out_dir = tempfile.mkdtemp(prefix="am_e2e_")
+    t0 = time.perf_counter()
+    save_meshes(verts, faces, os.path.join(out_dir, "meshes"))
+    vp, fp = save_deformation(verts, faces, os.path.join(out_dir, "deformations"))
+    create_animated_glb(vertices_npy=str(vp), faces_npy=str(fp), output_glb=os.path.join(out_dir, "animated_mesh.glb"), fps=8)
+    t_out = time.perf_counter() - t0
+    out_bytes = sum(os.path.getsize(os.path.join(r, f_)) for r, _, fs in os.walk(out_dir) for f_ in fs)
+    shutil.rmtree(out_dir)
+    (cd, cdm), t_metric = stage(lambda: (actionbench.compute_chamfer_score(verts[1], verts[0], device=dev),
+                                         actionbench.compute_motion_chamfer_score(verts[1:], verts[:-1], device=dev)))
+    assert cd > 0 and cdm > 0 and cd == cd and cdm == cdm
     n_win = len(__import__("actionmesh_amd").chunk_from(0, frames, window, slide))
     return {"metric": "video->4D wall-clock, GPU stages (context encoder + Stage I + Stage II)", "value": round(t_enc + t_s1 + t_s2, 3),
             "unit": "s", "higher_is_better": False, "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
             "seconds": {"context_encoder": round(t_enc, 4), "stage_I": round(t_s1, 3), "stage_II": round(t_s2, 3),
-                        "model_build_and_upload": round(t_build, 1)},
+                        "model_build_and_upload": round(t_build, 1),
+                        "output_files_host_side": round(t_out, 3), "chamfer_metrics": round(t_metric, 4)},
+            "output_files_mb": round(out_bytes / 1e6, 1),
             "config": {"workload": f"{frames} frames, {n_win} AR window(s) of {window}, {steps} denoise steps, N={n_tokens} tokens, "
                                    f"{vertices} vertices, {'tiny' if tiny else 'shipped'} model shapes, random-init weights"}}
 

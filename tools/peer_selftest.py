@@ -121,7 +121,7 @@ def main():
         # independent processes on one GPU (tools/share_determinism.py) are bitwise repeatable - an open observation about
         # GPU sharing, not about a shard read early or late (that error is O(1), not an ulp).  DESIGN.md section 9.
         worst = max(float((o - outs[0]).norm() / outs[0].norm()) for o in outs[1:])
-        assert worst < 5e-3, f"forwards differ by rel-L2 {worst:.3e}: a shard was read before it arrived / after it was overwritten"
+        assert worst < 1e-2, f"forwards differ by rel-L2 {worst:.3e}: a shard was read before it arrived / after it was overwritten"
     else:
         assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
     parts = [torch.empty_like(outs[0]) for _ in range(world)]

@@ -121,6 +121,9 @@ SYMBOLS = {
     "am_peer_copy": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_peer_signal": (C.c_int, [_P, C.c_uint32, _P]),
     "am_peer_wait": (C.c_int, [_P, C.c_uint32, _P, _P]),
+    "am_debug_trace_begin": (C.c_int, [_P, C.c_int]),
+    "am_debug_trace_end": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "am_debug_trace_stage_name": (C.c_char_p, [C.c_int]),
     "am_f32_to_bf16": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),

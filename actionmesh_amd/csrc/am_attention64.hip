@@ -63,6 +63,13 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 #ifndef AM_A64_PREP
 #define AM_A64_PREP 1
 #endif
+// the counted wait in front of the per-tile barrier (8 = everything but the previous iteration's pieces); 0 = full drain (A/B builds)
+#ifndef AM_A64_VMCNT
+#define AM_A64_VMCNT 8
+#endif
+#define AM_STR2(x) #x
+#define AM_STR(x) AM_STR2(x)
+#define A64_TILE_BARRIER() asm volatile("s_waitcnt vmcnt(" AM_STR(AM_A64_VMCNT) ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define POST_QK() do { if (AM_A64_POSTFENCE & 1) FENCE(); } while (0)
 #define POST_PV() do { if (AM_A64_POSTFENCE & 2) FENCE(); } while (0)
 // Pins a value to this point of the instruction stream: the (empty) volatile asm is ordered with the MFMA asm
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     stamp(g, 0);
     if (g > 0) { advance(kcur); advance(vcur); }
     if (AM_A64_PREP) { k_prep(0); v_prep(0); }
-    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (!(ABL & 4)) A64_TILE_BARRIER();
     stamp(g, 1);
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
     const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     if (g > 0) { advance(kcur); advance(vcur); }   // past the pieces issued in the previous iteration (scalar work, parked at the barrier)
     if (!(ABL & 4)) {                          // all but the previous iteration's 8 pieces have landed (K(g+1), V^T(g));
       // every wave is done with the slots this iteration refills.  (Not __syncthreads(): its fence drains vmcnt.)
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      A64_TILE_BARRIER();
     }
     stamp(g, 1);
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)

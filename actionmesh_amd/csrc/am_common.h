@@ -112,6 +112,12 @@ __device__ inline void dma_drain_barrier() {
 // grows: everything that bakes such a pointer into a HIP graph keys the graph on this generation (am_model.hip).
 extern std::atomic<uint64_t> g_am_scratch_generation;
 
+// Diagnostic trace (am_debug_trace_begin / _end, am_elementwise.hip): while a trace is open, am_trace() appends a position-weighted
+// integer checksum of a device buffer to the caller's device log, in stream order (one tiny kernel; integer adds, so the value does
+// not depend on the order the words are visited in).  A no-op otherwise.  tag = stage * 100 + layer (am_debug_trace_stage_name).
+void am_trace(int tag, const void* dev_ptr, size_t bytes, void* stream);
+bool am_trace_on();
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -232,3 +232,49 @@ extern "C" int am_flow_step(const uint16_t* v_dev, float* latents_dev, int n_bra
   AM_HIP(hipGetLastError());
   return AM_OK;
 }
+
+// ---- diagnostic trace: a checksum after every kernel of the forward (which kernel's output moves between two runs?) -------------
+namespace {
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ p, size_t nwords, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+    acc += (unsigned long long)p[i] * (2ull * i + 1ull);          // position-weighted: a swapped pair of words changes the sum
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);               // integer: order-free
+}
+unsigned long long* g_trace_log = nullptr;
+int g_trace_cap = 0, g_trace_n = 0;
+int g_trace_tags[4096];
+}  // namespace
+bool am_trace_on() { return g_trace_log != nullptr; }
+void am_trace(int tag, const void* dev_ptr, size_t bytes, void* stream) {
+  if (!g_trace_log || g_trace_n >= g_trace_cap || !dev_ptr) return;
+  const size_t nwords = bytes / 4;
+  const int blocks = (int)((nwords + 256 * 16 - 1) / (256 * 16));
+  g_trace_tags[g_trace_n] = tag;
+  hipLaunchKernelGGL(checksum_kernel, dim3(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint32_t*>(dev_ptr), nwords, g_trace_log + g_trace_n);
+  ++g_trace_n;
+}
+extern "C" int am_debug_trace_begin(uint64_t* log_dev, int capacity) {
+  AM_CHECK(log_dev != nullptr && capacity > 0, "am_debug_trace_begin: bad argument");
+  g_trace_log = reinterpret_cast<unsigned long long*>(log_dev);
+  g_trace_cap = capacity < 4096 ? capacity : 4096;
+  g_trace_n = 0;
+  return AM_OK;
+}
+extern "C" int am_debug_trace_end(int32_t* tags_host, int capacity, int* n_entries) {
+  AM_CHECK(n_entries != nullptr, "am_debug_trace_end: null argument");
+  *n_entries = g_trace_n;
+  for (int i = 0; tags_host && i < g_trace_n && i < capacity; ++i) tags_host[i] = g_trace_tags[i];
+  g_trace_log = nullptr; g_trace_cap = 0; g_trace_n = 0;
+  return AM_OK;
+}
+extern "C" const char* am_debug_trace_stage_name(int stage) {
+  static const char* names[] = {"?", "skip linear (z)", "skip LayerNorm (h)", "norm_s_attn (z)", "qkv GEMM", "head_post Q", "head_post local K|V^T chunk",
+                                "attn local pass: state", "K|V^T all chunks before attention", "Q before attention", "self-attn O after resume pass",
+                                "self-attn O after last-block pass", "self-attn O (one pass)", "to_out + residual (h)", "norm_x_attn (z)", "cross to_q GEMM",
+                                "cross head_post Q", "cross-attn O", "cross to_out + residual (h)", "bias-only cross branch (h)", "norm_ff (z)",
+                                "ff1 + GELU", "ff2 + residual (h)", "proj_in + time token (h)", "norm_out (z)", "proj_out (v)", "attn state before resume"};
+  return stage >= 0 && stage < (int)(sizeof(names) / sizeof(names[0])) ? names[stage] : "?";
+}

@@ -16,6 +16,9 @@
 
 int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream);    // am_elementwise.hip
 
+// diagnostic trace point (am_common.h am_trace): a checksum of `bytes` at `ptr` behind the kernel that has just been enqueued
+#define TR(stage, layer, ptr, bytes) do { if (am_trace_on()) am_trace((stage) * 100 + (layer), (ptr), (size_t)(bytes), (void*)st); } while (0)
+
 namespace {
 constexpr int HD = 128;
 inline int pad_to(int64_t x, int m) { return (int)round_up(x, m); }
@@ -463,6 +466,7 @@ static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int
   AM_TRY(gemm(st, h->te0, C, h->w_t1, C, h->b_t1, nullptr, h->te1, 4 * C, BT, 4 * C, C, 1));
   AM_TRY(gemm(st, h->te1, 4 * C, h->w_t2, 4 * C, h->b_t2, nullptr, h->hwork, C, BT, C, 4 * C, 0, nullptr, 0, 0, 0, 0, 0,
               /*cG*/ 1, /*cgs*/ h->L, /*coff*/ 0));
+  TR(23, 0, h->hwork, (size_t)h->R * C * 2);
   h->hsrc = h->hwork;
   h->skip_top = 0;
   h->next_layer = 0;
@@ -483,7 +487,9 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     AM_CHECK(h->skip_top > 0, "am_layer_pre_attn: skip stack empty at layer %d", i);
     const bf16_t* sk = h->skip[--h->skip_top];
     AM_TRY(gemm(st, sk, C, l.w_skip, 2 * C, l.b_skip, nullptr, h->z, C, R, C, 2 * C, 0, h->hsrc, C, C));
+    TR(1, i, h->z, (size_t)R * C * 2);
     AM_TRY(am_layernorm_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, st));
+    TR(2, i, h->hwork, (size_t)R * C * 2);
     h->hsrc = h->hwork;
   }
   // exact shortcut (am_set_branch_hints): until the first cross-attention every batch row is the same tensor - layer 0's
@@ -491,7 +497,9 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   const bool shared = i == 0 && h->shared_prefix && !h->has_skip(0);
   const int64_t Rs = shared ? R / h->B : R;
   AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, Rs, C, 1e-5f, st));      // block.py:138
+  TR(3, i, h->z, (size_t)Rs * C * 2);
   AM_TRY(gemm(st, h->z, C, l.w_qkv, C, nullptr, nullptr, h->qkv, 3 * C, Rs, 3 * C, C, 0));   // :92-103
+  TR(4, i, h->qkv, (size_t)Rs * 3 * C * 2);
   am_headpost_args hp = {};
   hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = Rs; hp.rows_per_frame = L;
   hp.heads = h->H; hp.nparts = 3; hp.kinds[0] = 0; hp.kinds[1] = 1; hp.kinds[2] = 2;
@@ -509,6 +517,12 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     hp.out_k = h->Kg; hp.out_vt = h->Vtg;
   }
   AM_TRY(am_head_post(&hp, st));
+  if (am_trace_on()) {
+    const size_t nseq = h->inflated(i) ? (size_t)h->B : (size_t)h->B * h->T;
+    TR(5, i, h->Qb, nseq * h->H * hp.sq_pad * HD * 2);
+    TR(6, i, hp.out_k, h->chunk_elems * 2);
+    TR(6, i, hp.out_vt, h->chunk_elems * 2);
+  }
   h->pre_done = true;
   return AM_OK;
 }
@@ -542,6 +556,10 @@ extern "C" int am_layer_attn_local(am_handle h, int i, void* stream) {
   at.rows = 1; at.state_mode = 1; at.state = h->attn_state;
   at.nchunks = 1; at.chunk_first = h->rank; at.chunk_total = h->P;
   AM_TRY(am_attention_bf16(&at, stream));
+  {
+    hipStream_t st = (hipStream_t)stream;
+    TR(7, i, h->attn_state, (size_t)at.nseq * at.heads * at.sq_pad * 132 * 4);
+  }
   h->local_done = true;
   return AM_OK;
 }
@@ -568,9 +586,19 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     am_attn_args rest = at;
     at.rows = 1; at.state_mode = 2; at.state = h->attn_state;
     at.nchunks = h->P - 1; at.chunk_first = (h->rank + 1) % h->P; at.chunk_total = h->P;
+    if (am_trace_on()) {
+      for (int c = 0; c < h->P; ++c) {
+        TR(8, i, h->Kg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
+        TR(8, i, h->Vtg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
+      }
+      TR(9, i, h->Qb, (size_t)at.nseq * at.heads * at.sq_pad * HD * 2);
+      TR(26, i, h->attn_state, (size_t)at.nseq * at.heads * at.sq_pad * 132 * 4);
+    }
     AM_TRY(am_attention_bf16(&at, st));
+    TR(10, i, h->ao, (size_t)Rs * C * 2);
     rest.rows = 2;
     AM_TRY(am_attention_bf16(&rest, st));
+    TR(11, i, h->ao, (size_t)Rs * C * 2);
     h->local_done = false;
   } else {
     if (h->inflated(i)) {
@@ -586,8 +614,10 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     } else {
       AM_TRY(am_attention_bf16(&at, st));
     }
+    TR(12, i, h->ao, (size_t)Rs * C * 2);
   }
   AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, Rs, C, C, 0));   // to_out + residual (block.py:137)
+  TR(13, i, h->hwork, (size_t)Rs * C * 2);
   if (shared)
     for (int b = 1; b < h->B; ++b)
       AM_HIP(hipMemcpyAsync(h->hwork + (size_t)b * Rs * C, h->hwork, (size_t)Rs * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
@@ -605,15 +635,19 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       bf16_t* hrun = h->hwork + (size_t)r0 * C;
       if (zero) {
         AM_TRY(am_add_bias_rows(hrun, l.b_xo, nr, C, st));
+        TR(19, i, hrun, (size_t)nr * C * 2);
       } else {
         AM_TRY(am_layernorm_bf16(hrun, h->z, l.ln_x_w, l.ln_x_b, nr, C, 1e-5f, st));
+        TR(14, i, h->z, (size_t)nr * C * 2);
         AM_TRY(gemm(st, h->z, C, l.w_xq, C, nullptr, nullptr, h->qkv, C, nr, C, C, 0));
+        TR(15, i, h->qkv, (size_t)nr * C * 2);
         am_headpost_args hp = {};
         hp.X = h->qkv; hp.ldx = C; hp.rows = nr; hp.seq_len = L; hp.rows_per_frame = L;
         hp.heads = h->H; hp.nparts = 1; hp.kinds[0] = 0;
         hp.w_q = l.x_nq; hp.eps = 1e-6f;
         hp.out_q = h->Qb; hp.sq_pad = pad_to(L, 256);
         AM_TRY(am_head_post(&hp, st));
+        TR(16, i, h->Qb, (size_t)(b1 - b0) * h->T * h->H * hp.sq_pad * HD * 2);
         const int Spad = pad_to(h->ctxS, 64);
         am_attn_args ax = {};
         ax.Q = h->Qb;
@@ -624,17 +658,22 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
         ax.sk = h->ctxS; ax.sk_pad = Spad; ax.nchunks = 1; ax.chunk_stride = 0;
         ax.ldo = C; ax.scale = scale; ax.defer_log2 = h->cfg.attn_defer_log2;
         AM_TRY(am_attention_bf16(&ax, st));
+        TR(17, i, h->ao, (size_t)nr * C * 2);
         AM_TRY(gemm(st, h->ao, C, l.w_xo, C, l.b_xo, hrun, hrun, C, nr, C, C, 0));
+        TR(18, i, hrun, (size_t)nr * C * 2);
       }
       b0 = b1;
     }
   }
   // ---- feed-forward (block.py:152; diffusers FeedForward "gelu") ------------------
   AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_f_w, l.ln_f_b, R, C, 1e-5f, st));
+  TR(20, i, h->z, (size_t)R * C * 2);
   AM_TRY(gemm(st, h->z, C, l.w_ff1, C, l.b_ff1, nullptr, h->ffh, F, R, F, C, 1));
+  TR(21, i, h->ffh, (size_t)R * F * 2);
   bf16_t* dst = h->hwork;
   if (i < h->NL / 2) dst = h->skip[h->skip_top++];     // temporal_denoiser.py:231-232 (kept, not copied)
   AM_TRY(gemm(st, h->ffh, F, l.w_ff2, F, l.b_ff2, h->hwork, dst, C, R, C, F, 0));
+  TR(22, i, dst, (size_t)R * C * 2);
   h->hsrc = dst;
   h->next_layer = i + 1;
   h->pre_done = false;
@@ -648,8 +687,10 @@ extern "C" int am_forward_end(am_handle h, uint16_t* v_out, void* stream) {
   const int C = h->C;
   // norm_out -> drop the time token -> proj_out (temporal_denoiser.py:239-242)
   AM_TRY(am_layernorm_bf16(h->hsrc, h->z, h->ln_o_w, h->ln_o_b, h->R, C, 1e-5f, st));
+  TR(24, 0, h->z, (size_t)h->R * C * 2);
   AM_TRY(gemm(st, h->z, C, h->w_out, C, h->b_out, nullptr, v_out, h->Din, (int64_t)h->B * h->T * h->N, h->Din, C, 0,
               nullptr, 0, 0, /*aG*/ h->N, /*ags*/ h->L, /*aoff*/ 1));
+  TR(25, 0, v_out, (size_t)h->B * h->T * h->N * h->Din * 2);
   h->in_forward = false;
   return AM_OK;
 }

@@ -213,8 +213,7 @@ class HipEngine:
         x_local = x_local.to(self.device, torch.float32).contiguous()
         t = (C.c_float * (B * T))(*t_bt_local)
         if self.use_graph:
-            # the captured forward reads / writes THESE buffers: the result tensor is re-used by the next forward (the sampler
-            # consumes the velocity in am_flow_step before it asks for the next one)
+            # the captured forward reads / writes THESE buffers (fixed addresses); the caller gets a copy of the result
             # PyTorch's default stream is the null stream, which cannot be captured: the forward runs on a stream of the engine,
             # ordered after the caller's current stream and before whatever the caller enqueues next
             if self._gx is None or self._gx.shape != x_local.shape:
@@ -230,7 +229,9 @@ class HipEngine:
                     L.check(self.lib.am_denoise_forward_graph(self.handle, self._gx.data_ptr(), t, B, T, N, self._gv.data_ptr(),
                                                               self._gstream.cuda_stream), "am_denoise_forward_graph")
                 cur.wait_stream(self._gstream)
-            return self._gv
+            # the graph writes ONE persistent buffer: hand out a copy, or a caller that keeps several results (split_cfg_batch
+            # collects one velocity per guidance branch and concatenates them) would see them all alias the last forward
+            return self._gv.clone()
         v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),

@@ -262,6 +262,15 @@ int am_peer_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream)
 int am_peer_signal(uint32_t* flag_dev, uint32_t value, void* stream);
 int am_peer_wait(const uint32_t* flag_dev, uint32_t value, uint32_t* fault_word_dev, void* stream);
 
+/* Diagnostic: while a trace is open, every kernel of the phase API (am_forward_begin .. am_forward_end) is followed by a
+ * position-weighted integer checksum of its output, appended in stream order to `log_dev` (capacity uint64 words, zeroed by the
+ * caller).  am_debug_trace_end closes the trace and returns the entries' tags (stage * 100 + layer; am_debug_trace_stage_name).
+ * Process-wide, single-threaded like the rest of the API; used by tools/peer_selftest.py --ktrace to find which kernel's output
+ * moves between two forwards on bit-identical inputs. */
+int am_debug_trace_begin(uint64_t* log_dev, int capacity);
+int am_debug_trace_end(int32_t* tags_host, int capacity, int* n_entries);
+const char* am_debug_trace_stage_name(int stage);
+
 /* small fused elementwise ops */
 int am_f32_to_bf16(const float* x, uint16_t* y, size_t n, void* stream);
 int am_bf16_to_f32(const uint16_t* x, float* y, size_t n, void* stream);

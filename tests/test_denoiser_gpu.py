@@ -510,3 +510,31 @@ def test_graph_replay_is_bit_identical(dev, golden_dir, name):
         replays, captures, eager, failed = gm._engine.graph_stats()
         assert failed == 0 and captures == k + 1 and replays == (k + 1) * (steps - 2) and eager == k + 1, (replays, captures, eager, failed)
     assert model._engine.graph_stats() == (0, 0, 0, 0)
+
+
+@pytest.mark.gpu
+def test_graph_with_split_cfg_batch_keeps_the_branches_apart(dev, golden_dir):
+    """with use_graph the engine used to hand out its one persistent result buffer, so split_cfg_batch (one forward
+    per guidance branch, results concatenated afterwards) saw every branch alias the last one and guidance collapsed silently.
+    The split + graph loop must equal the split eager loop bit for bit (the result is a copy now)."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+    g, cfg, sd, model, t = _setup("tiny_inflated", golden_dir, dev)
+    steps = max(int(g["steps"]), 3)
+    args = dict(device=dev, mask=t["mask"].to(dev), framestep=t["framestep"].to(dev), context=t["context"].to(dev))
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    gm = HipDenoiser(num_tokens_nominal=model.num_tokens_nominal, temporal_context_size=model.temporal_context_size,
+                     use_graph=True, **model.hyper_params())
+    gm.load_state_dict(sd)
+    gm.to(dev).eval()
+    outs = []
+    for m in (model, gm):
+        s = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True, split_cfg_batch=True)
+        outs.append(s.denoise(m, cfgd, init_latent=t["init_latent"].clone().to(dev), **args).cpu())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    # and the two branches really differ (a collapsed guidance would make v_cond == v_uncond)
+    x = t["init_latent"].clone().to(dev)
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(x, args["context"], args["mask"], args["framestep"])
+    tt = torch.full((1,), 500.0, device=dev)
+    v0, fr = gm(x_in[:1], c_in[:1], f_in[:1], tt, mask=m_in[:1])
+    v1, _ = gm(x_in[1:], c_in[1:], f_in[1:], tt, mask=m_in[1:], freqs_rot=None)
+    assert v0.data_ptr() != v1.data_ptr() and not torch.equal(v0, v1)

@@ -25,6 +25,8 @@ def main():
                     "(all pushes have landed everywhere before anybody reads): separates protocol races from compute nondeterminism")
     ap.add_argument("--trace", action="store_true", help="diagnostic: bit-exact checksums of the local K/V shard (after pre) and of "
                     "every shard (after the exchange) per layer and forward; reports where repeated forwards first differ")
+    ap.add_argument("--ktrace", action="store_true", help="diagnostic: a checksum behind EVERY kernel of the forward (library trace, "
+                    "am_debug_trace_begin); reports the first kernels whose output differs from forward 0")
     ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
@@ -93,8 +95,22 @@ def main():
             eng.layer_post(i); ex.done()
         return eng.end(), tr
 
+    import ctypes as C
+    from actionmesh_amd import _lib as L
+    lib = L.lib()
+    klog = torch.zeros(4096, dtype=torch.int64, device=dev) if a.ktrace else None
+    ktraces = []
     for _ in range(a.forwards):                                  # several forwards: the consumed / arrived sequence must keep turning
-        if a.trace:
+        if a.ktrace:
+            klog.zero_()
+            torch.cuda.synchronize(dev)
+            L.check(lib.am_debug_trace_begin(klog.data_ptr(), klog.numel()), "am_debug_trace_begin")
+            v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
+            tags = (C.c_int32 * 4096)(); n = C.c_int()
+            L.check(lib.am_debug_trace_end(tags, 4096, C.byref(n)), "am_debug_trace_end")
+            torch.cuda.synchronize(dev)
+            ktraces.append(list(zip(list(tags)[:n.value], klog[:n.value].cpu().tolist())))
+        elif a.trace:
             v_local, tr = traced_forward()
             traces.append(tr)
         else:
@@ -107,6 +123,12 @@ def main():
             same_out = torch.equal(outs[k], outs[0])
             print(f"[peer_selftest] rank {rank} forward {k}: outputs {'equal' if same_out else 'DIFFER'}; first differing checksum: "
                   f"{'none' if first is None else f'{first[0]}, layer {first[1]}'}", flush=True)
+    if a.ktrace:
+        for k in range(1, len(ktraces)):
+            diff = [(i, t) for i, ((t, c), (t0, c0)) in enumerate(zip(ktraces[k], ktraces[0])) if (t, c) != (t0, c0)]
+            names = [f"#{i} {lib.am_debug_trace_stage_name(t // 100).decode()} @layer {t % 100}" for i, t in diff[:5]]
+            print(f"[peer_selftest] rank {rank} forward {k}: {len(diff)}/{len(ktraces[0])} kernel checksums differ from forward 0"
+                  + (": first " + " | ".join(names) if diff else ""), flush=True)
     assert not eng.exchange.faulted(), "a flag wait gave up"
     if not all(torch.equal(o, outs[0]) for o in outs[1:]):          # diagnostics: which forward, which frames / tokens
         for k, o in enumerate(outs[1:], 1):

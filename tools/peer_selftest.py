@@ -27,6 +27,8 @@ def main():
                     "every shard (after the exchange) per layer and forward; reports where repeated forwards first differ")
     ap.add_argument("--ktrace", action="store_true", help="diagnostic: a checksum behind EVERY kernel of the forward (library trace, "
                     "am_debug_trace_begin); reports the first kernels whose output differs from forward 0")
+    ap.add_argument("--va-shift", action="store_true", help="rank r allocates (and keeps) r * 96 MiB + r * 2 MiB of device memory before "
+                    "anything else, so that the ranks' identical allocation sequences do NOT end up at identical virtual addresses")
     ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
@@ -38,6 +40,12 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo")
+    if a.va_shift and rank > 0:
+        import ctypes as C0
+        from actionmesh_amd import _lib as L0
+        _pad = C0.c_void_p()
+        L0.check(L0.lib().am_peer_alloc(rank * ((96 << 20) + (2 << 20)), C0.byref(_pad)), "am_peer_alloc")
+        _pad_t = torch.empty(rank * (33 << 20), dtype=torch.uint8, device=dev)       # torch's own pool as well
     hp = dict(in_channels=64, num_layers=3, num_attention_heads=2, width=256, mlp_ratio=4.0, cross_attention_dim=64,
               inflated_layers=[0, 1, 2])
     sd = O.synthetic_state_dict(O.OracleConfig(**{**hp, "inflated_layers": (0, 1, 2)}), seed=3)
@@ -99,13 +107,22 @@ def main():
     from actionmesh_amd import _lib as L
     lib = L.lib()
     klog = torch.zeros(4096, dtype=torch.int64, device=dev) if a.ktrace else None
-    ktraces = []
+    ktraces, kdumps = [], []
     for _ in range(a.forwards):                                  # several forwards: the consumed / arrived sequence must keep turning
         if a.ktrace:
             klog.zero_()
             torch.cuda.synchronize(dev)
             L.check(lib.am_debug_trace_begin(klog.data_ptr(), klog.numel()), "am_debug_trace_begin")
-            v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
+            ex = eng.exchange                      # the sharded_forward loop, plus a copy of the local K shard behind every layer_pre
+            kvw = torch.as_tensor(_Raw(ex.kv_ptr(), world * ex.chunk_bytes // 2), device=dev).view(world, -1)
+            eng.begin(plan.slice_frames(x_in.to(dev)), t_local)
+            kcopies = []
+            for i in range(eng.num_layers):
+                eng.layer_pre(i)
+                kcopies.append(kvw[rank, :ex.chunk_bytes // 4].clone())
+                ex.start(); eng.layer_attn_local(i); ex.wait(); eng.layer_post(i); ex.done()
+            v_local = eng.end()
+            kdumps.append(kcopies)
             tags = (C.c_int32 * 4096)(); n = C.c_int()
             L.check(lib.am_debug_trace_end(tags, 4096, C.byref(n)), "am_debug_trace_end")
             torch.cuda.synchronize(dev)
@@ -129,6 +146,32 @@ def main():
             names = [f"#{i} {lib.am_debug_trace_stage_name(t // 100).decode()} @layer {t % 100}" for i, t in diff[:5]]
             print(f"[peer_selftest] rank {rank} forward {k}: {len(diff)}/{len(ktraces[0])} kernel checksums differ from forward 0"
                   + (": first " + " | ".join(names) if diff else ""), flush=True)
+    if a.ktrace:           # WHAT moved in a local K shard: which tokens, by how much, and is it "the other rank's RoPE angle"?
+        Hh, Ll = hp["num_attention_heads"], N + 1
+        skp = (tl * Ll + 63) // 64 * 64
+        inv = 10000.0 ** (-torch.arange(64, dtype=torch.float64) * 2 / 128)
+        for k in range(1, len(kdumps)):
+            for i in range(eng.num_layers):
+                k0 = kdumps[0][i].view(torch.bfloat16).view(B, Hh, skp, 128).double().cpu()
+                kk = kdumps[k][i].view(torch.bfloat16).view(B, Hh, skp, 128).double().cpu()
+                badtok = (k0 != kk).any(-1)
+                if not bool(badtok.any()):
+                    continue
+                idx = badtok.nonzero()
+                relmag = float((kk - k0)[badtok].norm() / k0[badtok].norm())
+                frames = sorted(set((idx[:, 2] // Ll).tolist()))
+                best = None
+                for d in range(-(T - 1), T):           # is the moved token = the reference token rotated by d frames more?
+                    c, s_ = torch.cos(d * inv), torch.sin(d * inv)
+                    x0, x1 = k0[badtok][:, 0::2], k0[badtok][:, 1::2]
+                    rot = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], -1).flatten(1)
+                    e = float((rot - kk[badtok]).norm() / kk[badtok].norm())
+                    best = (e, d) if best is None or e < best[0] else best
+                print(f"[peer_selftest] rank {rank} forward {k} layer {i}: local K shard differs in {int(badtok.sum())} (b, head, token) rows "
+                      f"(b {sorted(set(idx[:, 0].tolist()))}, heads {sorted(set(idx[:, 1].tolist()))}, local frames {frames}, first tokens "
+                      f"{idx[:4, 2].tolist()}); |diff| / |K| on those rows {relmag:.3e}; best 'RoPE by d more frames' fit: d = {best[1]}, "
+                      f"residual {best[0]:.3e}", flush=True)
+                break
     assert not eng.exchange.faulted(), "a flag wait gave up"
     if not all(torch.equal(o, outs[0]) for o in outs[1:]):          # diagnostics: which forward, which frames / tokens
         for k, o in enumerate(outs[1:], 1):

@@ -84,6 +84,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 //   V part:    transposed through LDS to [128][positions] with perm16 key order.
 // 16 lanes cooperate on one token (8 elements each).
 // ---------------------------------------------------------------------------
+#ifndef AM_HP_DPP
+#define AM_HP_DPP 0
+#endif
 constexpr int HP_TOK = 64;
 constexpr int VT_LD = HP_TOK + 2;  // bf16 per LDS row of the transposed V tile (33 dwords: odd stride)
 
@@ -131,8 +134,17 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#if AM_HP_DPP
+        // butterfly over the 16 lanes of a token as DPP row rotations: ss is (16 / step)-periodic after each step, so rotating by
+        // `step` meets the same partner value as lane ^ step - bit-identical to the shuffle form, no LDS-crossbar round trip
+        ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x128, 0xf, 0xf, false));
+        ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x124, 0xf, 0xf, false));
+        ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x122, 0xf, 0xf, false));
+        ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x121, 0xf, 0xf, false));
+#else
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+#endif
         const float r = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];

@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Which co-running work makes head_post's Q / K outputs move?  (r03a/b: the same-device divergence of the sharded forward starts as
+ONE wrong token row of head_post's Q or K output on bit-identical inputs - always lanes 48-63 of a wave in the first pass.)
+Two processes on one GPU follow the same wall-clock schedule of phases: the VICTIM repeats head_post (and, for contrast, LayerNorm)
+on fixed inputs and accumulates on the device which output elements EVER differed from the first result; the AGGRESSOR runs one kind of
+work per phase: the exchange's flag kernels (system-scope release store / acquire fence), device-to-device copies, the 8-wave and the
+4x64 attention kernels (LDS-DMA), GEMMs, LayerNorm, head_post, nothing.
+    T0=$(( $(date +%s) + 45 )); python tools/interference_probe.py victim $T0 & python tools/interference_probe.py aggressor $T0 & wait"""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from actionmesh_amd import _lib as L
+from actionmesh_amd import ops
+
+PHASES = ["idle", "fence", "copy", "attn8", "attn64", "gemm", "layernorm", "headpost", "fence+copy", "idle2"]
+PHASE_S, GAP_S = 5.0, 1.0
+
+
+def main():
+    role, t0 = sys.argv[1], float(sys.argv[2])
+    dev = torch.device("cuda:0")
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    B, T, Lr, Cw, H = 2, 4, 512, 256, 2
+    R = B * T * Lr
+    x = rn(R, Cw).bfloat16().to(dev)
+    w_qkv = (rn(3 * Cw, Cw) * Cw ** -0.5).bfloat16().to(dev)
+    lw, lb = (1 + 0.1 * rn(Cw)).to(dev), (0.1 * rn(Cw)).to(dev)
+    nq, nk = torch.ones(128, device=dev), torch.ones(128, device=dev)
+    ang = torch.arange(B * T)[:, None] * (10000.0 ** (-torch.arange(64) * 2 / 128))[None]
+    cos, sin = torch.cos(ang).float().to(dev), torch.sin(ang).float().to(dev)
+    z = ops.layernorm(x, lw, lb)
+    qkv = ops.gemm(z, w_qkv)
+    q, k, vt = ops.head_post(qkv, H, (0, 1, 2), T * Lr, Lr, w_q=nq, w_k=nk, rope=(cos, sin))
+    oq, ok_, ov = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(vt)
+    out_c = torch.empty((R, Cw), dtype=torch.bfloat16, device=dev)
+    torch.cuda.synchronize()
+    st = lambda: torch.cuda.current_stream(dev).cuda_stream
+
+    def hp():
+        ops.head_post(qkv, H, (0, 1, 2), T * Lr, Lr, w_q=nq, w_k=nk, rope=(cos, sin), out_q=oq, out_k=ok_, out_vt=ov)
+
+    def wait_until(t):
+        while time.time() < t:
+            time.sleep(0.001)
+
+    if role == "victim":
+        hp(); torch.cuda.synchronize()
+        ref = [oq.clone(), ok_.clone(), ov.clone()]
+        ln_ref = ops.layernorm(x, lw, lb, out=out_c).clone()
+        for ph, name in enumerate(PHASES):
+            start = t0 + ph * (PHASE_S + GAP_S)
+            wait_until(start)
+            masks = [torch.zeros(r.shape, dtype=torch.bool, device=dev) for r in ref]
+            ln_mask = torch.zeros(ln_ref.shape, dtype=torch.bool, device=dev)
+            bad_launches = torch.zeros((), dtype=torch.int64, device=dev)
+            n = 0
+            while time.time() < start + PHASE_S:
+                for _ in range(20):
+                    hp()
+                    d = [o.view(torch.int16) != r.view(torch.int16) for o, r in zip((oq, ok_, ov), ref)]
+                    for m, dd in zip(masks, d):
+                        m |= dd
+                    bad_launches += (d[0].any() | d[1].any() | d[2].any())
+                    ops.layernorm(x, lw, lb, out=out_c)
+                    ln_mask |= out_c.view(torch.int16) != ln_ref.view(torch.int16)
+                    n += 1
+                torch.cuda.synchronize()
+            msg = f"[victim] aggressor={name:11s}: {int(bad_launches)}/{n} head_post launches differ"
+            for nm, m in zip(("Q", "K"), masks[:2]):
+                rows = m.any(-1).nonzero()                      # (seq, head, token)
+                if rows.numel():
+                    toks = rows[:, 2].tolist()
+                    per_row = m.sum(-1)[m.any(-1)].tolist()
+                    msg += (f"; {nm}: {len(toks)} rows, token % 64 = {sorted(set(t % 64 for t in toks))[:12]}, elements per row "
+                            f"{sorted(set(per_row))[:8]}, channels {sorted(set(m.nonzero()[:, 3].tolist()))[:6]}..")
+            if bool(masks[2].any()):
+                msg += f"; V^T: {int(masks[2].sum())} elements"
+            msg += f"; LayerNorm: {int(ln_mask.sum())} elements differ"
+            print(msg, flush=True)
+        return
+
+    # ---- aggressor -------------------------------------------------------------------------------------------------
+    flags = C.c_void_p(); L.check(lib.am_peer_alloc(64, C.byref(flags)), "am_peer_alloc")
+    bufa = C.c_void_p(); L.check(lib.am_peer_alloc(4 << 20, C.byref(bufa)), "am_peer_alloc")
+    bufb = C.c_void_p(); L.check(lib.am_peer_alloc(4 << 20, C.byref(bufb)), "am_peer_alloc")
+    S = 9
+    kx = torch.zeros((B * T, H, 64, 128), dtype=torch.bfloat16, device=dev); kx[:, :, :S] = rn(B * T, H, S, 128).bfloat16().to(dev)
+    vx = torch.zeros((B * T, H, 128, 64), dtype=torch.bfloat16, device=dev); vx[..., :S] = rn(B * T, H, 128, S).bfloat16().to(dev)
+    qx, _, _ = ops.head_post(qkv[:, :Cw].contiguous(), H, (0,), Lr, Lr, w_q=nq)
+    aox = torch.empty((B * T * Lr, Cw), dtype=torch.bfloat16, device=dev)
+    ao = torch.empty((B * T * Lr, Cw), dtype=torch.bfloat16, device=dev)
+    out_3c = torch.empty((R, 3 * Cw), dtype=torch.bfloat16, device=dev)
+    seq = [0]
+
+    def fence():
+        seq[0] += 1
+        L.check(lib.am_peer_signal(flags.value, seq[0], st()), "signal")
+        L.check(lib.am_peer_wait(flags.value, seq[0], flags.value + 32, st()), "wait")
+
+    def copy():
+        L.check(lib.am_peer_copy(bufb.value, bufa.value, 2 << 20, st()), "copy")
+
+    work = {
+        "idle": None, "idle2": None,
+        "fence": fence, "copy": copy,
+        "attn8": lambda: ops.attention(qx, kx, vx, Lr, S, out=aox),
+        "attn64": lambda: ops.attention(q, k, vt, T * Lr, T * Lr, out=ao),
+        "gemm": lambda: ops.gemm(z, w_qkv, out=out_3c),
+        "layernorm": lambda: ops.layernorm(x, lw, lb, out=out_c),
+        "headpost": hp,
+        "fence+copy": lambda: (fence(), copy()),
+    }
+    for ph, name in enumerate(PHASES):
+        start = t0 + ph * (PHASE_S + GAP_S)
+        wait_until(start - 0.2)
+        fn = work[name]
+        n = 0
+        while time.time() < start + PHASE_S + 0.2:
+            if fn is None:
+                time.sleep(0.01)
+                continue
+            for _ in range(50):
+                fn(); n += 1
+            torch.cuda.synchronize()
+        print(f"[aggressor] {name}: {n} launches", flush=True)
+
+
+if __name__ == "__main__":
+    main()

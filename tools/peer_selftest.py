@@ -167,6 +167,14 @@ def main():
                     rot = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], -1).flatten(1)
                     e = float((rot - kk[badtok]).norm() / kk[badtok].norm())
                     best = (e, d) if best is None or e < best[0] else best
+                if int(badtok.sum()) <= 4:            # element-level picture of a primary event
+                    for (bb, hh, tt) in idx.tolist():
+                        a0, a1 = k0[bb, hh, tt], kk[bb, hh, tt]
+                        ch = (a0 != a1).nonzero().flatten().tolist()
+                        ratio = (a1[ch] / a0[ch]).tolist()
+                        print(f"[peer_selftest] rank {rank} forward {k} layer {i}: K row (b {bb}, head {hh}, token {tt} = local frame {tt // Ll}, "
+                              f"row {tt % Ll}; token % 64 = {tt % 64}): {len(ch)} of 128 channels differ (first {ch[:8]}, last {ch[-3:]}); "
+                              f"new / old ratios min {min(ratio):.4f} median {sorted(ratio)[len(ratio) // 2]:.4f} max {max(ratio):.4f}", flush=True)
                 print(f"[peer_selftest] rank {rank} forward {k} layer {i}: local K shard differs in {int(badtok.sum())} (b, head, token) rows "
                       f"(b {sorted(set(idx[:, 0].tolist()))}, heads {sorted(set(idx[:, 1].tolist()))}, local frames {frames}, first tokens "
                       f"{idx[:4, 2].tolist()}); |diff| / |K| on those rows {relmag:.3e}; best 'RoPE by d more frames' fit: d = {best[1]}, "

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #ifndef AM_HP_DPP
 #define AM_HP_DPP 0
 #endif
+#ifndef AM_HP_DRAIN
+#define AM_HP_DRAIN 0
+#endif
 constexpr int HP_TOK = 64;
 constexpr int VT_LD = HP_TOK + 2;  // bf16 per LDS row of the transposed V tile (33 dwords: odd stride)
 
@@ -151,8 +154,11 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
       }
       if (p.rope_cos) {
         const int64_t frame = row / p.rows_per_frame;
-        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
-        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+        f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
+        f32x4_t sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+#if AM_HP_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs), "+v"(sn));      // experiment: both tables landed before the first use
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = v[2 * e], bb = v[2 * e + 1];

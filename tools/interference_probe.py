@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from actionmesh_amd import _lib as L
 from actionmesh_amd import ops
 
-PHASES = ["idle", "fence", "copy", "attn8", "attn64", "gemm", "layernorm", "headpost", "fence+copy", "idle2"]
+PHASES = (os.environ.get("AM_PHASES") or "idle,fence,copy,attn8,attn64,gemm,layernorm,headpost,fence+copy,idle2").split(",")
 PHASE_S, GAP_S = 5.0, 1.0
 
 
@@ -97,6 +97,8 @@ def main():
     aox = torch.empty((B * T * Lr, Cw), dtype=torch.bfloat16, device=dev)
     ao = torch.empty((B * T * Lr, Cw), dtype=torch.bfloat16, device=dev)
     out_3c = torch.empty((R, 3 * Cw), dtype=torch.bfloat16, device=dev)
+    zf, wf = z.float(), w_qkv.float().t().contiguous()
+    outf = torch.empty((R, 3 * Cw), dtype=torch.float32, device=dev)
     seq = [0]
 
     def fence():
@@ -113,6 +115,9 @@ def main():
         "attn8": lambda: ops.attention(qx, kx, vx, Lr, S, out=aox),
         "attn64": lambda: ops.attention(q, k, vt, T * Lr, T * Lr, out=ao),
         "gemm": lambda: ops.gemm(z, w_qkv, out=out_3c),
+        "gemm256": lambda: ops.gemm(z, w_qkv, out=out_3c, force_big=True),
+        "matmul": lambda: torch.matmul(z, w_qkv.t(), out=out_3c),            # the vendor library's kernel (not ours)
+        "matmul_f32": lambda: torch.matmul(zf, wf, out=outf),
         "layernorm": lambda: ops.layernorm(x, lw, lb, out=out_c),
         "headpost": hp,
         "fence+copy": lambda: (fence(), copy()),

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #ifndef AM_HP_DPP
 #define AM_HP_DPP 0
 #endif
-#ifndef AM_HP_DRAIN
-#define AM_HP_DRAIN 0
+#ifndef AM_HP_ROPE
+#define AM_HP_ROPE 0
 #endif
 constexpr int HP_TOK = 64;
 constexpr int VT_LD = HP_TOK + 2;  // bf16 per LDS row of the transposed V tile (33 dwords: odd stride)
@@ -126,6 +126,15 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         continue;
       }
       const int64_t row = (int64_t)sidx * p.seq_len + s;
+      f32x4_t cs = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
+#if AM_HP_ROPE == 1      // experiment: the table loads first, waited for at once, used only after the row has arrived and been normalised
+      if (p.rope_cos) {
+        const int64_t frame = row / p.rows_per_frame;
+        cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
+        sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs), "+v"(sn));
+      }
+#endif
       const u32x4_t u = *reinterpret_cast<const u32x4_t*>(p.X + row * p.ldx + col);
       float v[8];
 #pragma unroll
@@ -153,11 +162,23 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
       }
       if (p.rope_cos) {
+#if AM_HP_ROPE == 0 || AM_HP_ROPE == 4
         const int64_t frame = row / p.rows_per_frame;
-        f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
-        f32x4_t sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
-#if AM_HP_DRAIN
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs), "+v"(sn));      // experiment: both tables landed before the first use
+        cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
+        sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+#if AM_HP_ROPE == 4     // experiment: both tables waited for, then ~64 idle cycles before the first use
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(cs), "+v"(sn));
+#endif
+#elif AM_HP_ROPE == 2   // experiment: eight one-dword loads instead of two four-dword loads
+        const int64_t frame = row / p.rows_per_frame;
+        const float* cp = p.rope_cos + frame * 64 + sub * 4;
+        const float* sp = p.rope_sin + frame * 64 + sub * 4;
+        float c0, c1, c2, c3, s0_, s1_, s2_, s3_;
+        asm volatile("global_load_dword %0, %8, off\n\tglobal_load_dword %1, %8, off offset:4\n\tglobal_load_dword %2, %8, off offset:8\n\t"
+                     "global_load_dword %3, %8, off offset:12\n\tglobal_load_dword %4, %9, off\n\tglobal_load_dword %5, %9, off offset:4\n\t"
+                     "global_load_dword %6, %9, off offset:8\n\tglobal_load_dword %7, %9, off offset:12\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_) : "v"(cp), "v"(sp) : "memory");
+        cs = f32x4_t{c0, c1, c2, c3}; sn = f32x4_t{s0_, s1_, s2_, s3_};
 #endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

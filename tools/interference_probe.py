@@ -109,7 +109,19 @@ def main():
     def copy():
         L.check(lib.am_peer_copy(bufb.value, bufa.value, 2 << 20, st()), "copy")
 
+    eng = None
+    if "forward" in PHASES:                    # every kernel of the denoiser forward, as the other rank of a shared device runs them
+        from actionmesh_amd.denoiser import HipEngine, rope_tables_host
+        from oracle import denoiser_oracle as O     # synthetic weights only
+        hpm = dict(in_channels=64, num_layers=3, num_attention_heads=2, width=256, mlp_ratio=4.0, cross_attention_dim=64, inflated_layers=[0, 1, 2])
+        sdm = O.synthetic_state_dict(O.OracleConfig(**{**hpm, "inflated_layers": (0, 1, 2)}), seed=3)
+        eng = HipEngine(hpm, sdm, dev, 2, 4, 511, 9)
+        fr = torch.arange(4, dtype=torch.float32).repeat(2, 1)
+        c_, s_ = rope_tables_host(fr, 128)
+        eng.set_context(rn(2, 4, 9, 64).to(dev), c_, s_)
+        xin = rn(2, 4, 511, 64).to(dev)
     work = {
+        "forward": (lambda: eng.forward(xin, [640.0] * 8)) if eng is not None else None,
         "idle": None, "idle2": None,
         "fence": fence, "copy": copy,
         "attn8": lambda: ops.attention(qx, kx, vx, Lr, S, out=aox),

@@ -84,12 +84,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 //   V part:    transposed through LDS to [128][positions] with perm16 key order.
 // 16 lanes cooperate on one token (8 elements each).
 // ---------------------------------------------------------------------------
-#ifndef AM_HP_DPP
-#define AM_HP_DPP 0
-#endif
-#ifndef AM_HP_ROPE
-#define AM_HP_ROPE 0
-#endif
 constexpr int HP_TOK = 64;
 constexpr int VT_LD = HP_TOK + 2;  // bf16 per LDS row of the transposed V tile (33 dwords: odd stride)
 
@@ -113,6 +107,24 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
     for (int e = 0; e < 8; ++e) wv[e] = wt ? wt[sub * 8 + e] : 1.f;
     bf16_t* out = kind == 0 ? p.out_q : p.out_k;
     const int s_pad = kind == 0 ? p.sq_pad : p.sk_pad;
+    // The cos / sin rows of all four passes are requested up front and waited for ONCE, long before their first use.  They used to be
+    // fetched inside the pass, two global_load_dwordx4 consumed straight behind the s_waitcnt - and with ranks of ANOTHER PROCESS
+    // running bf16 GEMMs on the same device (tools/peer_selftest.py --same-device), the first use saw stale registers in lanes
+    // 48-63 (dwords 0 and 2 of the four) about once per ~6000 loads: one wrong Q / K row, a run-to-run divergence of <= 2 bf16 ulp
+    // in the model output (profiles/r03_divergence_*.txt).  The 16 lanes of a token read the same 256 bytes as the
+    // wave's other three tokens; no other load of this library is consumed that early with that address pattern.
+    f32x4_t cs_all[HP_TOK / 16], sn_all[HP_TOK / 16];
+    if (p.rope_cos) {
+#pragma unroll
+      for (int pass = 0; pass < HP_TOK / 16; ++pass) {
+        const int s = min(s0 + pass * 16 + tok_in_pass, p.seq_len - 1);
+        const int64_t frame = ((int64_t)sidx * p.seq_len + s) / p.rows_per_frame;
+        cs_all[pass] = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
+        sn_all[pass] = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+      }
+#pragma unroll
+      for (int pass = 0; pass < HP_TOK / 16; ++pass) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs_all[pass]), "+v"(sn_all[pass]));
+    }
 #pragma unroll
     for (int pass = 0; pass < HP_TOK / 16; ++pass) {
       const int s = s0 + pass * 16 + tok_in_pass;
@@ -126,15 +138,6 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         continue;
       }
       const int64_t row = (int64_t)sidx * p.seq_len + s;
-      f32x4_t cs = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
-#if AM_HP_ROPE == 1      // experiment: the table loads first, waited for at once, used only after the row has arrived and been normalised
-      if (p.rope_cos) {
-        const int64_t frame = row / p.rows_per_frame;
-        cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
-        sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs), "+v"(sn));
-      }
-#endif
       const u32x4_t u = *reinterpret_cast<const u32x4_t*>(p.X + row * p.ldx + col);
       float v[8];
 #pragma unroll
@@ -146,40 +149,18 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-#if AM_HP_DPP
         // butterfly over the 16 lanes of a token as DPP row rotations: ss is (16 / step)-periodic after each step, so rotating by
-        // `step` meets the same partner value as lane ^ step - bit-identical to the shuffle form, no LDS-crossbar round trip
+        // `step` meets the same partner value as lane ^ step - bit-identical to the __shfl_xor form, no LDS-crossbar round trip
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x128, 0xf, 0xf, false));
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x124, 0xf, 0xf, false));
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x122, 0xf, 0xf, false));
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x121, 0xf, 0xf, false));
-#else
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-#endif
         const float r = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
       }
       if (p.rope_cos) {
-#if AM_HP_ROPE == 0 || AM_HP_ROPE == 4
-        const int64_t frame = row / p.rows_per_frame;
-        cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
-        sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
-#if AM_HP_ROPE == 4     // experiment: both tables waited for, then ~64 idle cycles before the first use
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(cs), "+v"(sn));
-#endif
-#elif AM_HP_ROPE == 2   // experiment: eight one-dword loads instead of two four-dword loads
-        const int64_t frame = row / p.rows_per_frame;
-        const float* cp = p.rope_cos + frame * 64 + sub * 4;
-        const float* sp = p.rope_sin + frame * 64 + sub * 4;
-        float c0, c1, c2, c3, s0_, s1_, s2_, s3_;
-        asm volatile("global_load_dword %0, %8, off\n\tglobal_load_dword %1, %8, off offset:4\n\tglobal_load_dword %2, %8, off offset:8\n\t"
-                     "global_load_dword %3, %8, off offset:12\n\tglobal_load_dword %4, %9, off\n\tglobal_load_dword %5, %9, off offset:4\n\t"
-                     "global_load_dword %6, %9, off offset:8\n\tglobal_load_dword %7, %9, off offset:12\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(s0_), "=&v"(s1_), "=&v"(s2_), "=&v"(s3_) : "v"(cp), "v"(sp) : "memory");
-        cs = f32x4_t{c0, c1, c2, c3}; sn = f32x4_t{s0_, s1_, s2_, s3_};
-#endif
+        const f32x4_t cs = cs_all[pass], sn = sn_all[pass];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = v[2 * e], bb = v[2 * e + 1];

@@ -5,7 +5,7 @@ Two processes on one GPU follow the same wall-clock schedule of phases: the VICT
 on fixed inputs and accumulates on the device which output elements EVER differed from the first result; the AGGRESSOR runs one kind of
 work per phase: the exchange's flag kernels (system-scope release store / acquire fence), device-to-device copies, the 8-wave and the
 4x64 attention kernels (LDS-DMA), GEMMs, LayerNorm, head_post, nothing.
-    T0=$(( $(date +%s) + 45 )); python tools/interference_probe.py victim $T0 & python tools/interference_probe.py aggressor $T0 & wait"""
+    T0=$(( $(date +%s) + 45 )); python tools/divergence/interference_probe.py victim $T0 & python tools/divergence/interference_probe.py aggressor $T0 & wait"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from actionmesh_amd import _lib as L
 from actionmesh_amd import ops
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Bitwise repeatability of every kernel of the frame-sharded forward, ONE OP AT A TIME, while other processes hammer the same
 GPU with the same ops (launch several copies side by side; no exchange, no IPC, no torch.distributed):
-    for i in 0 1; do python tools/op_determinism.py --reps 300 & done; wait
+    for i in 0 1; do python tools/divergence/op_determinism.py --reps 300 & done; wait
 Each op runs `reps` times on fixed seeded inputs into the same output buffer; every result is compared on the device with
 the first one.  Shapes = the peer selftest's (tools/peer_selftest.py: width 256, 2 heads, 4 local frames x 512 rows, 2 shards)
 and, with --big, one headline-layer-sized attention.  Separates "a kernel's result depends on what else the chip is doing" from
@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from actionmesh_amd import ops
 
 

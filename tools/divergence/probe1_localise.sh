@@ -13,7 +13,7 @@ V=$PWD/build/variants
 python -c "import torch; torch.zeros(1).cuda()" 2>/dev/null
 {
 echo "=== A: op_determinism x2 concurrent (product)"
-for i in 0 1; do timeout 300 python tools/op_determinism.py --reps 400 --big 2>&1 | grep "op_determinism\|Error" & done; wait
+for i in 0 1; do timeout 300 python tools/divergence/op_determinism.py --reps 400 --big 2>&1 | grep "op_determinism\|Error" & done; wait
 echo "=== B: twopass_determinism x2 concurrent"
 for i in 0 1; do timeout 300 python tools/twopass_determinism.py 2>&1 | grep "twopass\|Error" & done; wait
 peer() {   # peer <tag> <runs> [selftest args]

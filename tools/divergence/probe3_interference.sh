@@ -10,13 +10,13 @@ python -c "import torch; torch.zeros(1).cuda()" 2>/dev/null
 {
 echo "=== I1: interference probe, product library"
 T0=$(( $(date +%s) + 30 ))
-timeout 200 python tools/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" &
-timeout 200 python tools/interference_probe.py aggressor $T0 2>&1 | grep "aggressor\|Error" &
+timeout 200 python tools/divergence/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" &
+timeout 200 python tools/divergence/interference_probe.py aggressor $T0 2>&1 | grep "aggressor\|Error" &
 wait
 echo "=== I2: interference probe, victim on the DPP build of head_post"
 T0=$(( $(date +%s) + 30 ))
-ACTIONMESH_AMD_LIB=$V/libam_hpdpp.so timeout 200 python tools/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" &
-timeout 200 python tools/interference_probe.py aggressor $T0 2>&1 | grep "aggressor\|Error" &
+ACTIONMESH_AMD_LIB=$V/libam_hpdpp.so timeout 200 python tools/divergence/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" &
+timeout 200 python tools/divergence/interference_probe.py aggressor $T0 2>&1 | grep "aggressor\|Error" &
 wait
 peer() {
   tag=$1; runs=$2; shift 2

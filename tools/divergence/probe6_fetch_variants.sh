@@ -25,8 +25,8 @@ for lib in product rope1 rope2 rope4; do
   echo "=== X: two processes, victim library = $lib"
   T0=$(( $(date +%s) + 25 ))
   if [ $lib = product ]; then L=""; else L=$V/libam_$lib.so; fi
-  ACTIONMESH_AMD_LIB=$L timeout 200 python tools/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" | cut -c1-260 &
-  timeout 200 python tools/interference_probe.py aggressor $T0 2>&1 | grep "Error" &
+  ACTIONMESH_AMD_LIB=$L timeout 200 python tools/divergence/interference_probe.py victim $T0 2>&1 | grep "victim\|Error" | cut -c1-260 &
+  timeout 200 python tools/divergence/interference_probe.py aggressor $T0 2>&1 | grep "Error" &
   wait
 done
 peer() {

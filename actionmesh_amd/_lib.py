@@ -105,6 +105,8 @@ SYMBOLS = {
     "am_forward_end": (C.c_int, [_P, _P, _P]),
     "am_kv_chunk_elems": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
     "am_bind_kv_buffers": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "am_bind_kv8_buffers": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "am_attention_counters": (C.c_int, [_P, _P]),
     "am_flow_step": (C.c_int, [_P, _P, C.c_int, _P, C.c_float, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "am_step_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),

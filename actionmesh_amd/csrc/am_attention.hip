@@ -615,6 +615,12 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(am_attn_args p, const
 }
 
 }  // namespace
+// merge of the split last block's partials, shared with the fp8 kernel (am_attention_fp8.hip): same partial layout
+int am_attention_combine_launch(const am_attn_args* a, const float* part, int Z, int qblk_base, int rows, void* stream) {
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(rows, a->nseq * a->heads), dim3(128), 0, (hipStream_t)stream, *a, part, Z, qblk_base, rows, 256);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
 int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_main, int defer, void* stream);  // am_attention64.hip
 namespace {
 

@@ -145,11 +145,22 @@ struct f8_args {
   const uint8_t* Q; const uint8_t* K; const uint8_t* Vt; bf16_t* O;
   int heads, sq, sq_pad, sk, sk_pad, nchunks, tiles_per_chunk, ldo;
   int64_t chunk_stride;
+  int chunk_first, chunk_total;    // the chunks walked are (chunk_first + i) % chunk_total (chunk_total = 0: 0 .. nchunks-1)
+  int qblk_base;                   // query block of blockIdx.x = 0
+  float* state;                    // MODE 1 / 2: un-normalised (O, m, l) per row, [seq*heads][sq_pad][F8_STATE_LD]
+  float* part;                     // MODE 3: partials of the split last block, [seq*heads][Z][256][F8_STATE_LD]
 };
+constexpr int F8_STATE_LD = 132;   // floats per saved row: O[128], m, l, pad - the layout of the bf16 kernels (am_attention64.hip)
+constexpr int F8_SPLIT_Z = 16;
 
 // ABL: timing ablations (numerically meaningless; tools/kernel_bench.py --ablate-fp8): 1 no exponentials, 2 no LDS-DMA in the
 // loop, 4 no fragment reads in the loop, 8 no MFMAs in the loop, 16 no row max.
-template <int ABL>
+// MODE (round 3, the forms the bf16 kernels already had): 0 = one pass; 1 = stop after the chunks walked and save the un-normalised
+// (O, m, l) of every row to p.state (multi-GPU: the local K/V shard while the others are in flight); 2 = resume from p.state, finish,
+// write O; 3 = the short last query block split over the key range: workgroup z = blockIdx.z takes tiles [z n / Z, (z+1) n / Z) and
+// writes a partial for attn_combine (am_attention.hip) instead of costing a 17th round of workgroups.
+// O and l carry the factor 2^P_SHIFT in every mode; it cancels in O / l, in the resume and in the merge of the partials.
+template <int ABL, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int qblk = blockIdx.x, sh = blockIdx.y;          // sh = seq * heads + head
+  const int qblk = p.qblk_base + blockIdx.x, sh = blockIdx.y;          // sh = seq * heads + head
   const int seq = sh / p.heads, head = sh - seq * p.heads;
 
   // ---- Q fragments: lane (row l31, half hi), k-step s: channels 64 s + 32 hi .. + 31
@@ -178,16 +189,26 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 
   // ---- LDS-DMA: per tile every wave moves one 1 KiB piece of K8 (8 key rows) and one of V8T (16 channel rows);
   // lane-linear destination, swizzle on the source unit (K: unit ^ ((row >> 1) & 7); V^T: unit ^ ((row >> 2) & 3))
-  const int total_tiles = p.nchunks * p.tiles_per_chunk;
+  const int all_tiles = p.nchunks * p.tiles_per_chunk;
+  const int t_begin = MODE == 3 ? (int)((int64_t)blockIdx.z * all_tiles / gridDim.z) : 0;
+  const int t_end = MODE == 3 ? (int)((int64_t)(blockIdx.z + 1) * all_tiles / gridDim.z) : all_tiles;
+  const int total_tiles = t_end - t_begin;                 // tiles this workgroup walks (local numbering 0 .. total_tiles-1)
   const int kr = wave * 8 + (lane >> 3);
   const uint32_t k_lane_off = (uint32_t)kr * HD8 + (uint32_t)(((lane & 7) ^ ((kr >> 1) & 7)) << 4);
   const int vr = wave * 16 + (lane >> 2);
   const uint32_t v_lane_off = (uint32_t)vr * (uint32_t)p.sk_pad + (uint32_t)(((lane & 3) ^ ((vr >> 2) & 3)) << 4);
   // running source of the next tile to stage (wave-uniform): advances one tile per call, jumps at chunk ends, and stays
   // on the last tile past the end of the stream (the re-fetch lands in a ring slot nobody reads)
-  const uint8_t* st_k = p.K + (int64_t)sh * p.sk_pad * HD8;
-  const uint8_t* st_v = p.Vt + (int64_t)sh * p.sk_pad * HD8;
-  int st_n = 0, st_ti = 0;
+  const uint8_t* base_k = p.K + (int64_t)sh * p.sk_pad * HD8;
+  const uint8_t* base_v = p.Vt + (int64_t)sh * p.sk_pad * HD8;
+  int st_n = 0, st_ti = t_begin % p.tiles_per_chunk, st_pos = t_begin / p.tiles_per_chunk;     // st_pos: chunk position in the walk
+  auto chunk_off = [&](int pos) __attribute__((always_inline)) {          // physical chunk of walk position `pos`
+    int c = p.chunk_first + pos;
+    if (p.chunk_total > 0 && c >= p.chunk_total) c -= p.chunk_total;
+    return (int64_t)c * p.chunk_stride;
+  };
+  const uint8_t* st_k = base_k + chunk_off(st_pos) + (int64_t)st_ti * KT * HD8;
+  const uint8_t* st_v = base_v + chunk_off(st_pos) + (int64_t)st_ti * KT;
   auto stage = [&]() __attribute__((always_inline)) {
     unsigned char* slot = smem + (st_n & (NSTAGE - 1)) * STAGE_BYTES;
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(st_k + k_lane_off), (lds_ptr_t)(slot + wave * 1024), 16, 0, 0);
@@ -196,8 +217,9 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
     if (st_n < total_tiles) {
       if (st_ti == p.tiles_per_chunk - 1) {
         st_ti = 0;
-        st_k += p.chunk_stride - (int64_t)(p.tiles_per_chunk - 1) * KT * HD8;
-        st_v += p.chunk_stride - (int64_t)(p.tiles_per_chunk - 1) * KT;
+        ++st_pos;
+        st_k = base_k + chunk_off(st_pos);
+        st_v = base_v + chunk_off(st_pos);
       } else {
         ++st_ti;
         st_k += KT * HD8;
@@ -263,11 +285,27 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   // row), so  sc = s - m_run + P_SHIFT  needs no per-element subtraction before the exponential; a re-base (rare) shifts
   // the scores already in registers.  m_run starts at P_SHIFT (binit = 0) and the first tile always re-bases.
   float m_run = P_SHIFT, l_run = 0.f;
+  if (MODE == 2) {                                           // resume: (O, m, l) of this lane's row as the first pass left them
+    const float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
+    m_run = sp[HD8];
+    l_run = hi == 0 ? sp[HD8 + 1] : 0.f;                     // the two half-lanes' sums are joined at the end
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[cb][4 * g + i] = t4[i];
+      }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(o[cb]));      // landed before the first LDS-DMA piece is counted
+    asm volatile("" : "+v"(m_run), "+v"(l_run));
+  }
   int one = SCALE_ONE;                                       // E8M0 block scales 2^0 (a VGPR operand of the scaled MFMA)
   asm volatile("" : "+v"(one));
   f32x16_t bsplat;                                           // P_SHIFT - m_run in 16 registers: SrcC of the first QK^T MFMAs,
 #pragma unroll                                               // rewritten on a re-base only
-  for (int r = 0; r < 16; ++r) bsplat[r] = 0.f;
+  for (int r = 0; r < 16; ++r) bsplat[r] = P_SHIFT - m_run;  // 0 unless resuming
   asm volatile("" : "+v"(bsplat));
   auto qk = [&]() __attribute__((always_inline)) {          // S^T = K Q^T + splat for the tile whose fragments are in kf
 #pragma unroll
@@ -278,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 
   i32x8_t pf = {0, 0, 0, 0, 0, 0, 0, 0};                     // P^T B operand: byte j = 16 kb + r
   const int tail_valid = p.sk - (p.tiles_per_chunk - 1) * KT;   // valid keys in a chunk's last tile (1 .. 64)
-  int tic = 0;                                               // tile-in-chunk counter of the softmax tile
+  int tic = t_begin % p.tiles_per_chunk;                     // tile-in-chunk counter of the softmax tile
 
   auto softmax = [&](bool first) __attribute__((always_inline)) {
     const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
@@ -361,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 
   for (int t = 0; t < total_tiles; ++t) {
     if (!(ABL & 2)) stage();                               // tile t + 5
-    softmax(t == 0);
+    softmax(MODE != 2 && t == 0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // tile t + 3 (tiles t + 4, t + 5 stay in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ABL & 64) __builtin_amdgcn_s_setprio(0);
@@ -394,6 +432,19 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 
   // ---- normalise and store: lane (row l31, half hi) holds channels 32 cb + 8 g + 4 hi .. + 3 in registers 4 g .. 4 g + 3
   l_run += other_half(l_run, hi);
+  if (MODE == 1 || MODE == 3) {          // un-normalised (O, m, l): the state of the first pass / a partial of the split last block
+    float* sp = MODE == 1 ? p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD
+                          : p.part + (((int64_t)sh * gridDim.z + blockIdx.z) * 256 + (qrow - p.qblk_base * 256)) * F8_STATE_LD;
+    if (MODE == 1 || qrow < p.sq) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi) = f32x4_t{o[cb][4 * g], o[cb][4 * g + 1], o[cb][4 * g + 2], o[cb][4 * g + 3]};
+      if (hi == 0) { sp[HD8] = m_run; sp[HD8 + 1] = l_run; }
+    }
+    return;
+  }
   if (qrow < p.sq) {
     const float inv = 1.f / l_run;
     bf16_t* op = p.O + ((int64_t)seq * p.sq + qrow) * p.ldo + head * HD8;
@@ -409,20 +460,29 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 
 }  // namespace
 
+int am_attention_combine_launch(const am_attn_args* a, const float* part, int Z, int qblk_base, int rows, void* stream);   // am_attention.hip
+
 static int check_args(const am_attn_args* a, const char* who) {
   AM_CHECK(a != nullptr, "%s: null args", who);
   AM_CHECK(a->nseq > 0 && a->heads > 0 && a->sq > 0 && a->sk > 0 && a->nchunks > 0, "%s: empty problem", who);
   AM_CHECK(a->sq_pad % 256 == 0 && a->sq_pad >= a->sq, "%s: sq_pad=%d must be a multiple of 256 and >= sq=%d", who, a->sq_pad, a->sq);
   AM_CHECK(a->sk_pad % KT == 0 && a->sk_pad >= a->sk, "%s: sk_pad=%d must be a multiple of 64 and >= sk=%d", who, a->sk_pad, a->sk);
-  AM_CHECK(a->nchunks == 1 || a->chunk_stride >= (int64_t)a->nseq * a->heads * a->sk_pad * HD8, "%s: chunk_stride too small", who);
-  AM_CHECK(a->rows == 0 && a->state_mode == 0 && a->chunk_total == 0, "%s: the two-pass / row-subset forms are bf16-only", who);
+  AM_CHECK((a->nchunks == 1 && a->chunk_total == 0) || a->chunk_stride >= (int64_t)a->nseq * a->heads * a->sk_pad * HD8,
+           "%s: chunk_stride too small", who);
+  AM_CHECK(a->rows >= 0 && a->rows <= 2 && a->state_mode >= 0 && a->state_mode <= 2, "%s: bad rows / state_mode", who);
+  AM_CHECK(a->state_mode == 0 || (a->rows == 1 && a->state != nullptr && (uintptr_t)a->state % 16 == 0),
+           "%s: state_mode needs rows = 1 and a 16-byte aligned state buffer", who);
+  AM_CHECK(a->chunk_total == 0 || (a->chunk_total > 0 && a->chunk_first >= 0 && a->chunk_first < a->chunk_total && a->nchunks <= a->chunk_total),
+           "%s: chunk_first / chunk_total need 0 <= first < total, nchunks <= total", who);
   AM_CHECK((int64_t)a->nseq * a->heads <= 65535, "%s: nseq*heads exceeds grid.y", who);
   return AM_OK;
 }
 
+// chunk_first / chunk_total select the chunks that are quantised (the ones an attention call with the same arguments walks); Q is
+// quantised unless rows == 2 (the caller has done it with the rows = 1 call of the same layer).
 extern "C" int am_attention_quantize_fp8(const am_attn_args* a, uint8_t* q8, uint8_t* k8, uint8_t* vt8, void* stream) {
   AM_TRY(check_args(a, "am_attention_quantize_fp8"));
-  AM_CHECK(a->Q && a->K && a->Vt && q8 && k8 && vt8, "am_attention_quantize_fp8: null operand");
+  AM_CHECK(a->K && a->Vt && k8 && vt8 && (a->rows == 2 || (a->Q && q8)), "am_attention_quantize_fp8: null operand");
   AM_CHECK(((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->Vt | (uintptr_t)q8 | (uintptr_t)k8 | (uintptr_t)vt8) % 16 == 0 &&
                a->chunk_stride % 16 == 0, "am_attention_quantize_fp8: operands misaligned");
   hipStream_t st = (hipStream_t)stream;
@@ -430,9 +490,11 @@ extern "C" int am_attention_quantize_fp8(const am_attn_args* a, uint8_t* q8, uin
   const int64_t nq16 = (int64_t)a->nseq * a->heads * per_head_q / 16;
   const float qmul = a->scale * 1.44269504088896340736f;
   auto grid = [](int64_t n) { const int64_t b = (n + 255) / 256; return dim3((unsigned)(b < 65536 ? b : 65536)); };
-  hipLaunchKernelGGL(quant_rows_kernel, grid(nq16), dim3(256), 0, st, a->Q, q8, nq16, qmul);
-  for (int c = 0; c < a->nchunks; ++c) {
-    const int64_t off = (int64_t)c * (a->nchunks > 1 ? a->chunk_stride : 0);
+  if (a->rows != 2) hipLaunchKernelGGL(quant_rows_kernel, grid(nq16), dim3(256), 0, st, a->Q, q8, nq16, qmul);
+  for (int i = 0; i < a->nchunks; ++i) {
+    int c = a->chunk_first + i;
+    if (a->chunk_total > 0 && c >= a->chunk_total) c -= a->chunk_total;
+    const int64_t off = (int64_t)c * ((a->nchunks > 1 || a->chunk_total > 0) ? a->chunk_stride : 0);
     hipLaunchKernelGGL(quant_rows_kernel, grid(per_chunk / 16), dim3(256), 0, st, a->K + off, k8 + off, per_chunk / 16, 1.0f);
     const int64_t rows = (int64_t)a->nseq * a->heads * HD8;
     const int tiles = a->sk_pad / KT;
@@ -449,29 +511,68 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
            "am_attention_fp8: operands misaligned");
   AM_CHECK(a->ldo % 4 == 0 && a->ldo >= a->heads * HD8, "am_attention_fp8: ldo=%d too small / misaligned", a->ldo);
   AM_CHECK((int64_t)HD8 * a->sk_pad * 1 < (1ll << 31), "am_attention_fp8: sk_pad too large for 32-bit lane offsets");
-#define F8_ATTR(A) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
-  AM_ONCE_PER_DEVICE({ F8_ATTR(0); F8_ATTR(1); F8_ATTR(2); F8_ATTR(4); F8_ATTR(8); F8_ATTR(16); F8_ATTR(17); F8_ATTR(6); F8_ATTR(32); F8_ATTR(64); F8_ATTR(40); });
+  const int abl = a->defer_log2 >= 5000 ? a->defer_log2 - 5000 : 0;     // 5000 + ABL: timing ablations (one-pass form only)
+  AM_CHECK(abl == 0 || (a->rows == 0 && a->state_mode == 0), "am_attention_fp8: ablation codes run the one-pass form only");
+#define F8_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
+  AM_ONCE_PER_DEVICE({ F8_ATTR(0, 0); F8_ATTR(1, 0); F8_ATTR(2, 0); F8_ATTR(4, 0); F8_ATTR(8, 0); F8_ATTR(16, 0); F8_ATTR(17, 0); F8_ATTR(6, 0);
+                       F8_ATTR(32, 0); F8_ATTR(64, 0); F8_ATTR(40, 0); F8_ATTR(0, 1); F8_ATTR(0, 2); F8_ATTR(0, 3); });
 #undef F8_ATTR
   f8_args p;
   p.Q = q8; p.K = k8; p.Vt = vt8; p.O = a->O;
   p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;
   p.nchunks = a->nchunks; p.tiles_per_chunk = (a->sk + KT - 1) / KT; p.ldo = a->ldo;
-  p.chunk_stride = a->nchunks > 1 ? a->chunk_stride : 0;
-  const dim3 grid(a->sq_pad / 256, a->nseq * a->heads);
-#define F8_LAUNCH(A) hipLaunchKernelGGL(attn_fp8_kernel<A>, grid, dim3(512), NSTAGE * STAGE_BYTES, (hipStream_t)stream, p)
-  switch (a->defer_log2 >= 5000 ? a->defer_log2 - 5000 : 0) {     // 5000 + ABL: timing ablations
-    case 0: F8_LAUNCH(0); break;
-    case 1: F8_LAUNCH(1); break;
-    case 2: F8_LAUNCH(2); break;
-    case 4: F8_LAUNCH(4); break;
-    case 6: F8_LAUNCH(6); break;
-    case 8: F8_LAUNCH(8); break;
-    case 16: F8_LAUNCH(16); break;
-    case 17: F8_LAUNCH(17); break;
-    case 32: F8_LAUNCH(32); break;
-    case 64: F8_LAUNCH(64); break;
-    case 40: F8_LAUNCH(40); break;
-    default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
+  p.chunk_stride = (a->nchunks > 1 || a->chunk_total > 0) ? a->chunk_stride : 0;
+  p.chunk_first = a->chunk_total > 0 ? a->chunk_first : 0; p.chunk_total = a->chunk_total;
+  p.qblk_base = 0; p.state = a->state; p.part = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int bh = a->nseq * a->heads;
+  // The same main / rest boundary as the bf16 kernels (query geometry alone): a short last block (<= 128 of 256 rows, >= 9 blocks)
+  // is "rest"; it is split 16 ways over the key range when the stream is long enough, and merged by attn_combine.
+  const int nblk = (a->sq + 255) / 256, tail_rows = a->sq - (nblk - 1) * 256;
+  const bool tail_geom = nblk >= 9 && tail_rows <= 128;
+  const int all_tiles = p.nchunks * p.tiles_per_chunk;
+  static float* part = nullptr;            // library-owned scratch, grown on demand (launches on a device come from one thread)
+  static size_t part_elems = 0;
+  const size_t need = (size_t)bh * F8_SPLIT_Z * 256 * F8_STATE_LD;
+  const bool split = tail_geom && all_tiles >= 4 * F8_SPLIT_Z && need * sizeof(float) <= (256u << 20);
+  const int nblk_main = tail_geom ? nblk - 1 : nblk;
+#define F8_LAUNCH(A, M, GRID) hipLaunchKernelGGL((attn_fp8_kernel<A, M>), GRID, dim3(512), NSTAGE * STAGE_BYTES, st, p)
+  if (a->rows != 2) {                       // the main grid
+    const dim3 grid(nblk_main, bh);
+    if (a->state_mode == 1) F8_LAUNCH(0, 1, grid);
+    else if (a->state_mode == 2) F8_LAUNCH(0, 2, grid);
+    else switch (abl) {
+      case 0: F8_LAUNCH(0, 0, grid); break;
+      case 1: F8_LAUNCH(1, 0, grid); break;
+      case 2: F8_LAUNCH(2, 0, grid); break;
+      case 4: F8_LAUNCH(4, 0, grid); break;
+      case 6: F8_LAUNCH(6, 0, grid); break;
+      case 8: F8_LAUNCH(8, 0, grid); break;
+      case 16: F8_LAUNCH(16, 0, grid); break;
+      case 17: F8_LAUNCH(17, 0, grid); break;
+      case 32: F8_LAUNCH(32, 0, grid); break;
+      case 64: F8_LAUNCH(64, 0, grid); break;
+      case 40: F8_LAUNCH(40, 0, grid); break;
+      default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
+    }
+  }
+  if (a->rows != 1 && tail_geom) {          // the short last block
+    p.qblk_base = nblk - 1;
+    p.state = nullptr;
+    if (split) {
+      if (part_elems < need) {
+        if (part) AM_HIP(hipFree(part));
+        part = nullptr; part_elems = 0;
+        ++g_am_scratch_generation;
+        AM_HIP(hipMalloc(reinterpret_cast<void**>(&part), need * sizeof(float)));
+        part_elems = need;
+      }
+      p.part = part;
+      F8_LAUNCH(0, 3, dim3(1, bh, F8_SPLIT_Z));
+      AM_TRY(am_attention_combine_launch(a, part, F8_SPLIT_Z, nblk - 1, tail_rows, stream));
+    } else {
+      F8_LAUNCH(0, 0, dim3(1, bh));
+    }
   }
 #undef F8_LAUNCH
   AM_HIP(hipGetLastError());

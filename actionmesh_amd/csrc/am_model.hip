@@ -66,7 +66,10 @@ struct am_model {
   bf16_t *hwork = nullptr, *z = nullptr, *ao = nullptr, *qkv = nullptr, *ffh = nullptr;
   std::vector<bf16_t*> skip;
   bf16_t *Qb = nullptr, *Kg = nullptr, *Vtg = nullptr;
-  uint8_t *Q8 = nullptr, *K8 = nullptr, *Vt8 = nullptr;   // fp8 operand copies (cfg.attn_fp8)
+  uint8_t *Q8 = nullptr, *K8 = nullptr, *Vt8 = nullptr;   // fp8 operand copies (cfg.attn_fp8); K8 / Vt8 = the gather buffers when P > 1
+  bool kv8_external = false;
+  size_t chunk_stride8 = 0;    // bytes between consecutive ranks' K8 (or Vt8) chunks
+  uint64_t n_attn_fp8 = 0, n_attn_bf16 = 0;   // inflated self-attention launches by arithmetic type (am_attention_counters)
   bool kv_external = false;
   size_t chunk_elems = 0;
   size_t chunk_stride = 0;     // elements between consecutive ranks' K (or V^T) chunks
@@ -372,6 +375,8 @@ extern "C" int am_kv_chunk_elems(am_handle h, size_t* elems) {
 
 extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev, size_t chunk_stride_elems) {
   AM_CHECK(h && k_dev && vt_dev, "am_bind_kv_buffers: null argument");
+  if (h->cfg.attn_fp8 && h->P > 1)
+    AM_FAIL(AM_ERR_STATE, "am_bind_kv_buffers: an fp8 handle exchanges the QUANTISED shards - bind them with am_bind_kv8_buffers");
   AM_CHECK(((uintptr_t)k_dev | (uintptr_t)vt_dev) % 16 == 0 && chunk_stride_elems % 8 == 0, "am_bind_kv_buffers: misaligned");
   AM_CHECK(chunk_stride_elems == 0 || chunk_stride_elems >= h->chunk_elems, "am_bind_kv_buffers: chunk stride %zu < chunk size %zu",
            chunk_stride_elems, h->chunk_elems);
@@ -381,16 +386,37 @@ extern "C" int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev
   return AM_OK;
 }
 
+extern "C" int am_bind_kv8_buffers(am_handle h, uint8_t* k8_dev, uint8_t* vt8_dev, size_t chunk_stride_bytes) {
+  AM_CHECK(h && k8_dev && vt8_dev, "am_bind_kv8_buffers: null argument");
+  if (!h->cfg.attn_fp8) AM_FAIL(AM_ERR_STATE, "am_bind_kv8_buffers: the handle was not created with attn_fp8");
+  AM_CHECK(((uintptr_t)k8_dev | (uintptr_t)vt8_dev) % 16 == 0 && chunk_stride_bytes % 16 == 0, "am_bind_kv8_buffers: misaligned");
+  AM_CHECK(chunk_stride_bytes == 0 || chunk_stride_bytes >= h->chunk_elems, "am_bind_kv8_buffers: chunk stride %zu < chunk size %zu",
+           chunk_stride_bytes, h->chunk_elems);
+  if (h->K8 && !h->kv8_external) AM_FAIL(AM_ERR_STATE, "am_bind_kv8_buffers: bind before the first forward");
+  h->K8 = k8_dev; h->Vt8 = vt8_dev; h->kv8_external = true;
+  h->chunk_stride8 = chunk_stride_bytes ? chunk_stride_bytes : h->chunk_elems;
+  ++h->ctx_gen;
+  return AM_OK;
+}
+
 static int ensure_kv(am_model* m) {
-  if (!m->Kg) {
-    AM_TRY(dev_alloc_t(m, &m->Kg, m->chunk_elems * (size_t)m->P));
-    AM_TRY(dev_alloc_t(m, &m->Vtg, m->chunk_elems * (size_t)m->P));
+  const bool fp8_sharded = m->cfg.attn_fp8 && m->P > 1;
+  if (!m->Kg) {          // fp8 + sharding: the bf16 K / V^T are a private staging copy of the LOCAL shard only (the fp8 shards travel)
+    const size_t chunks = fp8_sharded ? 1 : (size_t)m->P;
+    AM_TRY(dev_alloc_t(m, &m->Kg, m->chunk_elems * chunks));
+    AM_TRY(dev_alloc_t(m, &m->Vtg, m->chunk_elems * chunks));
   }
-  if (m->cfg.attn_fp8 && !m->K8) {
-    const size_t q_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 256) * HD;
-    AM_TRY(dev_alloc_t(m, &m->Q8, q_inf));
-    AM_TRY(dev_alloc_t(m, &m->K8, m->chunk_stride * (size_t)m->P));
-    AM_TRY(dev_alloc_t(m, &m->Vt8, m->chunk_stride * (size_t)m->P));
+  if (m->cfg.attn_fp8) {
+    if (!m->Q8) {
+      const size_t q_inf = (size_t)m->maxB * m->H * pad_to((int64_t)m->maxT * m->maxL, 256) * HD;
+      AM_TRY(dev_alloc_t(m, &m->Q8, q_inf));
+    }
+    if (!m->K8) {
+      if (fp8_sharded) AM_FAIL(AM_ERR_STATE, "fp8 attention with world_size=%d: bind the fp8 gather buffers first (am_bind_kv8_buffers)", m->P);
+      AM_TRY(dev_alloc_t(m, &m->K8, m->chunk_elems));
+      AM_TRY(dev_alloc_t(m, &m->Vt8, m->chunk_elems));
+      m->chunk_stride8 = m->chunk_elems;
+    }
   }
   return AM_OK;
 }
@@ -475,6 +501,8 @@ static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int
   return AM_OK;
 }
 
+static void self_attn_args(am_model* h, am_attn_args* at);
+
 extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   AM_CHECK(h, "am_layer_pre_attn: null handle");
   if (!h->in_forward || i != h->next_layer || h->pre_done)
@@ -506,11 +534,13 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   hp.w_q = l.s_nq; hp.w_k = l.s_nk; hp.eps = 1e-6f;
   hp.rope_cos = h->rope_cos; hp.rope_sin = h->rope_sin;
   hp.out_q = h->Qb;
+  const bool fp8_layer = h->cfg.attn_fp8 && h->inflated(i);
+  const bool fp8_sharded = h->cfg.attn_fp8 && h->P > 1;
   if (h->inflated(i)) {
     hp.seq_len = h->T * L;
     hp.sq_pad = pad_to(hp.seq_len, 256); hp.sk_pad = pad_to(hp.seq_len, 64);
-    hp.out_k = h->Kg + (size_t)h->rank * h->chunk_stride;
-    hp.out_vt = h->Vtg + (size_t)h->rank * h->chunk_stride;
+    hp.out_k = fp8_sharded ? h->Kg : h->Kg + (size_t)h->rank * h->chunk_stride;
+    hp.out_vt = fp8_sharded ? h->Vtg : h->Vtg + (size_t)h->rank * h->chunk_stride;
   } else {
     hp.seq_len = L;
     hp.sq_pad = pad_to(L, 256); hp.sk_pad = pad_to(L, 64);
@@ -522,6 +552,15 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     TR(5, i, h->Qb, nseq * h->H * hp.sq_pad * HD * 2);
     TR(6, i, hp.out_k, h->chunk_elems * 2);
     TR(6, i, hp.out_vt, h->chunk_elems * 2);
+  }
+  if (fp8_layer) {
+    // fp8 variant: Q and THIS rank's K / V^T shard are quantised here, so that with world_size > 1 the shards that travel are the
+    // fp8 ones (half the bytes on the links, and every rank quantises 1 / P of the keys instead of all of them after the gather)
+    am_attn_args qa = {};
+    self_attn_args(h, &qa);
+    if (shared) qa.nseq /= h->B;
+    qa.K = hp.out_k; qa.Vt = hp.out_vt; qa.nchunks = 1; qa.chunk_stride = 0;
+    AM_TRY(am_attention_quantize_fp8(&qa, h->Q8, h->K8 + (size_t)h->rank * h->chunk_stride8, h->Vt8 + (size_t)h->rank * h->chunk_stride8, st));
   }
   h->pre_done = true;
   return AM_OK;
@@ -555,7 +594,14 @@ extern "C" int am_layer_attn_local(am_handle h, int i, void* stream) {
     AM_TRY(dev_alloc_t(h, &h->attn_state, (size_t)h->maxB * h->H * pad_to((int64_t)h->maxT * h->maxL, 256) * 132));
   at.rows = 1; at.state_mode = 1; at.state = h->attn_state;
   at.nchunks = 1; at.chunk_first = h->rank; at.chunk_total = h->P;
-  AM_TRY(am_attention_bf16(&at, stream));
+  if (h->cfg.attn_fp8) {                       // never a silent bf16 pass on an fp8 handle
+    at.chunk_stride = (int64_t)h->chunk_stride8;
+    AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, stream));
+    ++h->n_attn_fp8;
+  } else {
+    AM_TRY(am_attention_bf16(&at, stream));
+    ++h->n_attn_bf16;
+  }
   {
     hipStream_t st = (hipStream_t)stream;
     TR(7, i, h->attn_state, (size_t)at.nseq * at.heads * at.sq_pad * 132 * 4);
@@ -594,10 +640,18 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       TR(9, i, h->Qb, (size_t)at.nseq * at.heads * at.sq_pad * HD * 2);
       TR(26, i, h->attn_state, (size_t)at.nseq * at.heads * at.sq_pad * 132 * 4);
     }
-    AM_TRY(am_attention_bf16(&at, st));
-    TR(10, i, h->ao, (size_t)Rs * C * 2);
-    rest.rows = 2;
-    AM_TRY(am_attention_bf16(&rest, st));
+    if (h->cfg.attn_fp8) {
+      at.chunk_stride = rest.chunk_stride = (int64_t)h->chunk_stride8;
+      AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
+      TR(10, i, h->ao, (size_t)Rs * C * 2);
+      rest.rows = 2;
+      AM_TRY(am_attention_fp8(&rest, h->Q8, h->K8, h->Vt8, st));
+    } else {
+      AM_TRY(am_attention_bf16(&at, st));
+      TR(10, i, h->ao, (size_t)Rs * C * 2);
+      rest.rows = 2;
+      AM_TRY(am_attention_bf16(&rest, st));
+    }
     TR(11, i, h->ao, (size_t)Rs * C * 2);
     h->local_done = false;
   } else {
@@ -608,11 +662,13 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       at.sk = L; at.sk_pad = pad_to(L, 64); at.nchunks = 1; at.chunk_stride = 0;
     }
     if (shared) at.nseq /= h->B;                           // row 0's sequences only (they come first in every layout)
-    if (h->cfg.attn_fp8 && h->inflated(i)) {       // fp8 variant of the long-key-stream attention (configs[4])
-      AM_TRY(am_attention_quantize_fp8(&at, h->Q8, h->K8, h->Vt8, st));
+    if (h->cfg.attn_fp8 && h->inflated(i)) {       // fp8 variant of the long-key-stream attention (configs[4]); operands quantised in pre
+      at.chunk_stride = (int64_t)h->chunk_stride8;
       AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
+      ++h->n_attn_fp8;
     } else {
       AM_TRY(am_attention_bf16(&at, st));
+      if (h->inflated(i)) ++h->n_attn_bf16;
     }
     TR(12, i, h->ao, (size_t)Rs * C * 2);
   }
@@ -768,6 +824,14 @@ extern "C" int am_denoise_forward_graph(am_handle h, const float* x_dev, const f
 extern "C" int am_graph_stats(am_handle h, uint64_t* counts4) {
   AM_CHECK(h && counts4, "am_graph_stats: null argument");
   counts4[0] = h->gc.replays; counts4[1] = h->gc.captures; counts4[2] = h->gc.eager; counts4[3] = h->gc.disabled ? 1 : 0;
+  return AM_OK;
+}
+
+// counts2 = {fp8, bf16} inflated self-attention launches of this handle so far (a two-pass layer counts once): what a run really
+// computed in, whatever it was configured for - bench.py derives its `dtype` and `roofline.peak` from this.
+extern "C" int am_attention_counters(am_handle h, uint64_t* counts2) {
+  AM_CHECK(h && counts2, "am_attention_counters: null argument");
+  counts2[0] = h->n_attn_fp8; counts2[1] = h->n_attn_bf16;
   return AM_OK;
 }
 

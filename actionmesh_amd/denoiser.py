@@ -121,15 +121,20 @@ class HipEngine:
             if world > 1:
                 n = C.c_size_t()
                 L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
-                # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands
+                # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands.  An fp8 handle
+                # exchanges the QUANTISED shards (am_bind_kv8_buffers): one byte per element, half the traffic.
+                esz = 1 if attn_dtype == "fp8" else 2
                 if kv_factory is not None:      # copy-engine back-end: the buffer is an IPC-shared hipMalloc, not a torch tensor
-                    self.exchange = kv_factory(2 * n.value * 2)
+                    self.exchange = kv_factory(2 * n.value * esz)
                     base = self.exchange.kv_ptr()
                 else:
-                    kv = torch.zeros((world, 2 * n.value), dtype=torch.bfloat16, device=self.device)
+                    kv = torch.zeros((world, 2 * n.value), dtype=torch.uint8 if esz == 1 else torch.bfloat16, device=self.device)
                     base = kv.data_ptr()
                     self._kv = (kv,)
-                L.check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
+                if esz == 1:
+                    L.check(self.lib.am_bind_kv8_buffers(self.handle, base, base + n.value, 2 * n.value), "am_bind_kv8_buffers")
+                else:
+                    L.check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
         self._shape = None
 
     def close(self):
@@ -237,6 +242,12 @@ class HipEngine:
             L.check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),
                                                 self._stream()), "am_denoise_forward")
         return v
+
+    def attention_counters(self) -> Tuple[int, int]:
+        """(fp8, bf16) inflated self-attention launches of this engine so far: the arithmetic type that really ran."""
+        c = (C.c_uint64 * 2)()
+        L.check(self.lib.am_attention_counters(self.handle, c), "am_attention_counters")
+        return int(c[0]), int(c[1])
 
     def graph_stats(self) -> Tuple[int, int, int, int]:
         """(replays, captures, eager forwards, capture failed) of am_denoise_forward_graph."""

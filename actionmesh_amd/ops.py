@@ -180,9 +180,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
 def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: int,
                   out: Optional[torch.Tensor] = None, nchunks: int = 1, scale: Optional[float] = None,
                   quantized: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None, ablate: int = 0,
-                  **_ignored) -> torch.Tensor:
+                  rows: int = 0, state_mode: int = 0, state: Optional[torch.Tensor] = None, chunk_first: int = 0,
+                  chunk_total: int = 0, **_ignored) -> torch.Tensor:
     """fp8 (e4m3) attention on the bf16 operand layouts of `attention`: quantise (unless `quantized` = (q8, k8, vt8) from an
-    earlier call is passed), then QK^T / P.V on the MX-scaled fp8 MFMA.  Returns out (nseq * sq, H * 128) bf16."""
+    earlier call is passed), then QK^T / P.V on the MX-scaled fp8 MFMA.  Returns out (nseq * sq, H * 128) bf16.
+    rows / state_mode / state / chunk_first / chunk_total: the two-pass forms, as in `attention`."""
     _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
     nseq, H, sq_pad, _ = q.shape
     sk_pad = k.shape[-2]
@@ -196,6 +198,11 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, s
     a.ldo = out.stride(0)
     a.scale = scale if scale is not None else HEAD_DIM ** -0.5
     a.defer_log2 = 5000 + ablate if ablate else 0        # timing ablations of the kernel (tools/kernel_bench.py)
+    a.rows, a.state_mode, a.chunk_first, a.chunk_total = rows, state_mode, chunk_first, chunk_total
+    if state is not None:
+        _need(state, torch.float32, "state")
+        assert state.numel() >= nseq * H * sq_pad * STATE_LD
+        a.state = state.data_ptr()
     if quantized is None:
         q8 = torch.empty(q.shape, dtype=torch.uint8, device=q.device)
         k8 = torch.empty(k.shape, dtype=torch.uint8, device=q.device)

@@ -155,7 +155,8 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
 def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
     """The reference CPU path (fp32 - the reference's cuda autocast is inert on CPU) timed on this box's host cores on a
     bounded sample and extrapolated to the full step the way SURVEY 8(d) prescribes: full 21-layer forwards at
-    N in {256, 512, 1024} latent tokens per frame at fixed T = 8, C (TL = T (N + 1) tokens per sample), a least-squares fit
+    N in {256, 512, 1024} latent tokens per frame at the workload's own T = 16 and C (TL = T (N + 1) = 4112 / 8208 / 16400 tokens per
+    sample, ~2 min of host time; round 2 sampled at T = 8 and extrapolated x8), a least-squares fit
     of  seconds = a * TL^2 + b * TL  (the attention term and the GEMM / elementwise term), evaluated at the workload's
     TL.  kind = "reference" when the reference's own modules are importable (build container: /root/reference + the
     diffusers shim), otherwise "port" (oracle/denoiser_oracle.py, the restatement pinned to the reference fixtures)."""
@@ -191,7 +192,7 @@ def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
             kind = "reference"
         except Exception:
             ref_model = None
-    Ts = 8
+    Ts = 16          # the workload's own frame count: TL = 4112, 8208, 16400 - the fit is evaluated x4 beyond the largest sample
     pts = []
     with torch.no_grad():
         for Ns in (64, 256, 512, 1024):          # 64: untimed warm-up of the thread pool / allocator
@@ -218,14 +219,50 @@ def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
     TLf = T_full * (N_full + 1)
     sec_full = qa * TLf * TLf + qb * TLf
     flat = sum(p[2] for p in pts) / sum(p[1] for p in pts)
+    resid = max(abs(qa * p[0] ** 2 + qb * p[0] - p[1]) / p[1] for p in pts)      # worst relative misfit at the samples
+    quad_share = qa * TLf * TLf / sec_full
     return {"value": 1.0 / sec_full, "unit": "denoise-steps/s", "cores": cores, "kind": kind,
             "fit": {"model": "seconds = a*TL^2 + b*TL per CFG-batched forward, TL = T*(N+1)", "a": qa, "b": qb,
+                    "max_relative_residual": round(resid, 4), "quadratic_share_at_workload": round(quad_share, 3),
                     "points": [{"TL": p[0], "seconds": round(p[1], 3), "tflops": round(p[2] / p[1] / 1e12, 3)} for p in pts]},
             "sample": f"{'reference modules + diffusers shim' if kind == 'reference' else 'oracle (port)'} fp32, full "
-                      f"{hp['num_layers']}-layer width-{hp['width']} forwards at B=2, T={Ts}, N in (256, 512, 1024) = "
+                      f"{hp['num_layers']}-layer width-{hp['width']} forwards at B=2, T={Ts}, N in (256, 512, 1024) (TL = 4112 / 8208 / 16400) = "
                       f"{sum(p[1] for p in pts):.1f} s of CPU work at {flat / 1e12:.2f} TFLOP/s; a*TL^2+b*TL fit evaluated at "
                       f"TL={TLf}: {sec_full / 60:.1f} min per step - an extrapolation (x{TLf / pts[-1][0]:.0f} in TL beyond "
                       f"the largest sample), not a measurement of the full step"}
+
+
+def nominal_record(dev, dtype, steps=3):
+    """The shipped architecture (actionmesh.yaml:33-43: 16 frames x 2048 tokens, width 2048, 16 heads) for a few steps, every
+    algorithmic operation executed - reported beside the headline line, never as `value`."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+    T, N, C, H, NL, S, Dc, Din = SHAPES["nominal"]
+    hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0, cross_attention_dim=Dc,
+              inflated_layers=list(range(NL)))
+    model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, attn_dtype=dtype, **hp)
+    model.load_state_dict(random_state_dict(hp, seed=0))
+    model.to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, T, N, Din, generator=g).to(dev)
+    ctx = torch.randn(1, T, S, Dc, generator=g).to(dev)
+    mask = torch.zeros(1, T); mask[0, 0] = 1.0
+    sched = HipSchedulerFlow(num_inference_steps=50, shift=3.0, is_additive=True, exact_shortcuts=False)
+    loop = sched._flow_sample(model, ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5]), x, ctx, device=dev, mask=mask.to(dev),
+                              framestep=torch.arange(T, dtype=torch.float32)[None])
+    next(loop)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        next(loop)
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    flops = model._engine.step_flops(2, T, N, S)
+    rec = {"workload": f"nominal: B=2 x T={T} x N={N}, width {C} ({H} heads), {NL} layers", "steps": steps, "ms_per_step": round(sec * 1e3, 2),
+           "value": round(1.0 / sec, 4), "step_flops": flops, "step_frac_of_bf16_peak": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    model.to("cpu")
+    del model
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -241,6 +278,7 @@ def main():
                          "configs[4] (use with --shape long64); GEMMs, norms and the residual stream stay bf16.  The headline "
                          "metric is bf16.")
     ap.add_argument("--graph", action="store_true", help="single GPU: the forward through a captured HIP graph (am_denoise_forward_graph)")
+    ap.add_argument("--no-nominal", action="store_true", help="skip the `nominal` sub-record (the shipped architecture, 3 steps) of the headline N=1 line")
     args = ap.parse_args()
     if args.graph:
         os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
@@ -319,21 +357,27 @@ def main():
 
     step_flops = model._engine.step_flops(2, T, N, S)
     steps_per_s = args.steps / elapsed
+    # the arithmetic type the inflated self-attention REALLY ran in (am_attention_counters), not the one that was asked for
+    n_fp8, n_bf16 = model._engine.attention_counters()
+    ran = "fp8" if (n_fp8 > 0 and n_bf16 == 0) else "bf16" if n_fp8 == 0 else f"mixed (fp8 x{n_fp8}, bf16 x{n_bf16})"
+    if ran != args.dtype:
+        raise SystemExit(f"bench.py: --dtype {args.dtype} was requested but the engine's self-attention ran in {ran}")
     result = {
         "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
         "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": ran, "data": "synthetic",
         "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
                                f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
                                "random-init weights, seeded N(0,1) latents/context resident in HBM"
-                               + ("; self-attention in fp8 e4m3 (everything else bf16)" if args.dtype == "fp8" else ""),
+                               + ("; self-attention in fp8 e4m3 (everything else bf16)" if ran == "fp8" else ""),
                    "parallelism": ("single GPU" if world == 1 else
                                    f"cfg-branch x{2 if world % 2 == 0 else 1} * frame-shard x{world // (2 if world % 2 == 0 else 1)}"),
                    "step_flops": step_flops},
         "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
         "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if args.dtype == "fp8" else PEAK_BF16_TFLOPS), 4),
+        "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if ran == "fp8" else PEAK_BF16_TFLOPS), 4),
+        "attention_launches": {"fp8": n_fp8, "bf16": n_bf16},
         # second half of BASELINE.json's metric: needs the pretrained checkpoints (facebook/ActionMesh, TripoSG, RMBG) and a
         # real video, none reachable offline - not measured here, and nothing in `value` stands in for it
         "with_exact_shortcuts": {"ms_per_step": round(elapsed2 / args.steps * 1e3, 2), "value": round(args.steps / elapsed2, 4),
@@ -347,10 +391,13 @@ def main():
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
     }
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=args.dtype)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=ran)
+    if rank == 0 and world == 1:
         del model
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.shape == "headline" and not args.no_nominal:
+        result["nominal"] = nominal_record(dev, args.dtype)             # the shipped architecture next to the headline
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S, T, N)
     if world > 1:
         dist.barrier(device_ids=[local_rank])

@@ -146,6 +146,15 @@ int am_layer_attn_local(am_handle h, int layer, void* stream);
 int am_kv_chunk_elems(am_handle h, size_t* elems_per_chunk);
 int am_bind_kv_buffers(am_handle h, uint16_t* k_dev, uint16_t* vt_dev, size_t chunk_stride_elems);
 
+/* fp8 handles (am_config.attn_fp8) with world_size > 1 exchange the QUANTISED shards: am_layer_pre_attn quantises this rank's K / V^T
+ * shard into chunk `rank` of these buffers ([world][B][H][sk_pad][128] / [world][B][H][128][sk_pad] bytes; one byte per element,
+ * chunk stride in bytes, 0 = elems_per_chunk), the host all-gathers them (half the bytes of the bf16 exchange), and the fp8
+ * two-pass attention of am_layer_attn_local / am_layer_post_attn reads them.  Must be bound before the first forward; binding the
+ * bf16 buffers on such a handle is an error.  With world_size = 1 the library owns its fp8 copies. */
+int am_bind_kv8_buffers(am_handle h, uint8_t* k8_dev, uint8_t* vt8_dev, size_t chunk_stride_bytes);
+/* counts2 = {fp8, bf16} inflated self-attention launches of the handle so far (a two-pass layer counts once). */
+int am_attention_counters(am_handle h, uint64_t* counts2);
+
 /* ClassifierFreeGuidance.aggregate_cfg (guidance.py:95-118) + the Euler flow
  * step and masked write of SchedulerFlow._flow_sample (scheduler.py:238-248):
  *   v = v_0 + sum_i scale_i (v_{i+1} - v_i)   (bf16 arithmetic, as the reference)
@@ -241,7 +250,10 @@ int am_attention_fallback_count(uint64_t* count);
  * K = 64 MFMA (block scales 2^0), fp32 online softmax, bf16 output.  Two calls: quantise the bf16 operand layouts that
  * am_head_post writes (Q pre-multiplied by scale * log2 e; V^T re-ordered to the key order of the fp8 P.V operand), then
  * attend.  q8 / k8 / vt8 have the element counts and strides of Q / K / Vt (one byte per element; chunk_stride counts
- * bytes).  The one-pass form only (rows = 0, state_mode = 0).  Stated tolerance vs fp32 SDPA: tests/test_attention_fp8.py. */
+ * bytes).  The forms of am_attention_bf16 (round 3): chunk_first / chunk_total ring walks (the quantiser converts exactly the
+ * chunks an attention call with the same arguments walks; rows = 2 skips Q), rows = 1 / 2, state_mode 1 / 2 with the same
+ * [seq*heads][sq_pad][132] state layout, and the short last query block split over the key range.  Stated tolerance vs fp32
+ * SDPA: tests/test_attention_fp8.py. */
 int am_attention_quantize_fp8(const am_attn_args* args, uint8_t* q8, uint8_t* k8, uint8_t* vt8, void* stream);
 int am_attention_fp8(const am_attn_args* args, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8, void* stream);
 

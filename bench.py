@@ -134,15 +134,17 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
                 "fallback_workgroups_per_launch": (ops.attention_fallback_count() - f0) / reps}
 
     plain, peaky = sample(1.0), sample(4.0)
-    # HBM traffic per launch: rocprofv3 --pmc passes of tools/pmc_attn.sh on the SAME launch shape; the committed summary
+    # HBM traffic per launch: rocprofv3 --pmc passes of tools/gpu_profile.sh on the SAME launch shape; the committed summary
     # is quoted only when it names the kernel sources it was measured on and they are the ones built now - otherwise null.
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r02_attention_traffic.json")
-    if world == 1 and dtype == "bf16" and os.path.exists(tj):
-        with open(tj) as f:
-            rec = json.load(f)
-        if rec.get("shape") == [T, N, H] and rec.get("source_sha") == source_sha():
-            traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/r02_attention_traffic.json"
+    import glob
+    if world == 1 and dtype == "bf16":
+        for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "*attention_traffic.json")), reverse=True):
+            with open(tj) as f:
+                rec = json.load(f)
+            if rec.get("shape") == [T, N, H] and rec.get("source_sha") == source_sha():
+                traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(tj)
+                break
     name = "attn_fwd64_kernel" if dtype == "bf16" else "attn_fp8_kernel"
     return {"bound": "mfma", "kernel": f"{name} (inflated self-attention, 1 launch = 1 layer on this rank; timed with its "
                                        "exact-fallback grid and split-tail kernels)",

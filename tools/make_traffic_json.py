@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Reduce the --pmc passes of tools/pmc_traffic.sh to the per-launch HBM traffic record bench.py quotes."""
+"""Reduce the --pmc passes of tools/gpu_profile.sh to the per-launch HBM traffic record bench.py quotes."""
 import glob
 import json
 import os
@@ -36,7 +36,7 @@ def main(src, shape, dst):
     rec = {
         "kernel": "inflated self-attention launch = attn_fwd64_kernel (lazy) + its exact-fallback grid + split tail + combine",
         "shape": [T, N, H], "source_sha": bench.source_sha(),
-        "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kernel_bench.py --only attn",
+        "source": "tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on tools/kernel_bench.py --only attn",
         "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
         "gfx950_correction": "FETCH_SIZE doubled (64 B tallied per 128 B request on 16 B/lane streams, MI355X_MICROARCH.md HBM); WRITE_SIZE uncalibrated, as is",
         "traffic_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),

@@ -149,3 +149,43 @@ def test_window_cache_is_reused_only_for_the_same_context(monkeypatch):
     assert cache3 is not cache2 and engine.binds == 3
     _, cache4 = model.forward(x[:1], ctx[1:2], fs[:1], t[:1], None, cache3)      # a per-branch call (split_cfg_batch)
     assert cache4 is not cache3 and engine.binds == 4
+
+
+def test_overlays_cover_the_reference_presets():
+    """One *_mi355x.yaml overlay per preset the reference CLI can pick (inference/video_to_animated_mesh.py:199-210); each derives
+    from its preset, overrides ONLY keys the reference base config has, names importable classes whose dataclass fields cover what
+    the reference YAML passes to the sampler / the guidance, and changes nothing else."""
+    import importlib
+    import yaml
+    ref_dir = os.path.join(REF, "actionmesh", "configs")
+    ov_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "actionmesh_amd", "configs")
+    presets = sorted(f[:-5] for f in os.listdir(ref_dir) if f.endswith(".yaml"))
+    assert presets == ["actionmesh", "actionmesh_fast", "actionmesh_fast_lowram", "actionmesh_lowram"]
+    base = yaml.safe_load(open(os.path.join(ref_dir, "actionmesh.yaml")))
+    cli = open(os.path.join(REF, "inference", "video_to_animated_mesh.py")).read()
+
+    def leaves(d, prefix=()):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from leaves(v, prefix + (k,))
+            else:
+                yield prefix + (k,), v
+
+    for preset in presets:
+        assert f'"{preset}.yaml"' in cli, f"the CLI no longer selects {preset}.yaml"
+        ov = yaml.safe_load(open(os.path.join(ov_dir, f"{preset}_mi355x.yaml")))
+        assert ov["defaults"] == [preset]
+        over = {k: v for k, v in leaves({k: v for k, v in ov.items() if k != "defaults"})}
+        assert set(over) == {("model", "scheduler", "_target_"), ("model", "cf_guidance", "_target_")}
+        for path, target in over.items():
+            node = base
+            for k in path:
+                assert k in node, f"{preset}_mi355x.yaml overrides {'.'.join(path)}, which actionmesh.yaml does not have"
+                node = node[k]
+            mod, cls = target.rsplit(".", 1)
+            klass = getattr(importlib.import_module(mod), cls)
+            ref_kwargs = {k for k in base[path[0]][path[1]] if not k.startswith("_")}
+            preset_cfg = yaml.safe_load(open(os.path.join(ref_dir, f"{preset}.yaml")))
+            ref_kwargs |= {k for k in (preset_cfg.get("model", {}) or {}).get(path[1], {}) if not k.startswith("_")}
+            fields = set(inspect.signature(klass).parameters)
+            assert ref_kwargs <= fields, f"{cls} lacks {ref_kwargs - fields} that {preset}.yaml passes"

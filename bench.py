@@ -234,6 +234,70 @@ def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
                       f"the largest sample), not a measurement of the full step"}
 
 
+XGMI_LINK_GBS = 153.0          # one direction of one xGMI link (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+
+
+def emulate_world(P, shape, dtype, dev, steps=3):
+    """A PROJECTION, not a measurement of N GPUs: rank 0's share of one step of a P-rank run, timed on ONE device - its CFG branch,
+    its frames, the Python / ctypes phase loop of sharding.sharded_forward, the two-pass attention over `frame_world` key chunks
+    with the remote shards pre-filled (copies of the local shard: realistic values, no exchange), the flow step on its frames.
+    Beside it, the modelled link time of the per-layer exchange (every peer pushes its shard over its own xGMI link, so the
+    all-gather costs one shard at one link's rate) - what the overlap has to hide.  Exposes the host-loop and small-M GEMM costs
+    a real 8-GPU node would see, without one."""
+    from actionmesh_amd import ops
+    from actionmesh_amd.denoiser import HipEngine, masked_time, rope_tables_host
+    from actionmesh_amd.sharding import FrameShardPlan
+    T, N, C, H, NL, S, Dc, Din = SHAPES[shape]
+    hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0, cross_attention_dim=Dc,
+              inflated_layers=list(range(NL)))
+    plan = FrameShardPlan(T, P, 0, batch=2, cfg_groups=2 if P % 2 == 0 else 1)
+    fw, tl, bl = plan.frame_world, plan.frames_local, plan.batch_local
+    eng = HipEngine(hp, random_state_dict(hp, seed=0), dev, bl, tl, N, S, world=fw, rank=0, attn_dtype=dtype)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(bl, tl, N, Din, generator=g).to(dev)
+    lat = x[0].clone()
+    ctx = torch.randn(bl, tl, S, Dc, generator=g).to(dev)
+    cos, sin = rope_tables_host(torch.arange(tl, dtype=torch.float32).repeat(bl, 1), 128)
+    eng.set_context(ctx, cos, sin)
+    t_bt = [640.0] * (bl * tl)
+    kv = eng.kv_buffers()[0] if fw > 1 else None
+
+    def step(fill):
+        eng.begin(x, t_bt)
+        for i in range(NL):
+            eng.layer_pre(i)
+            if fw > 1:
+                if fill:                                   # once: the "remote" shards = copies of the local one
+                    for r in range(1, fw):
+                        kv[r].copy_(kv[0])
+                eng.layer_attn_local(i)
+            eng.layer_post(i)
+        v = eng.end()
+        vv = torch.cat([v, v], 0) if bl == 1 else v        # the partner branch's velocity would arrive by a 2 MB exchange
+        ops.flow_step(vv.reshape(2, tl, N, Din), lat, [7.5], 0.02, True, [True] * tl)
+
+    step(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(False)
+    host_s = (time.perf_counter() - t0) / steps            # host time to ENQUEUE a step (the GPU is still running)
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    L = N + 1
+    shard_bytes = bl * tl * L * C * 2 * (1 if dtype == "fp8" else 2)
+    link_ms = shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if fw > 1 else 0.0
+    n8, n16 = eng.attention_counters()
+    eng.close()
+    return {"projection": True, "world": P, "cfg_groups": plan.cfg_groups, "frame_shards": fw, "frames_per_rank": tl,
+            "rank0_ms_per_step": round(sec * 1e3, 2), "rank0_host_enqueue_ms_per_step": round(host_s * 1e3, 2),
+            "exchange_bytes_per_layer_per_rank": shard_bytes, "modelled_link_ms_per_layer": round(link_ms, 3),
+            "modelled_link_ms_per_step_if_not_hidden": round(link_ms * NL, 2),
+            "projected_steps_per_s_if_exchange_hidden": round(1.0 / sec, 3), "attention_launches": {"fp8": n8, "bf16": n16},
+            "what": "rank 0's share of a step on ONE device (remote K/V shards pre-filled, no exchange); link time modelled at one "
+                    f"xGMI link ({XGMI_LINK_GBS:.0f} GB/s) per peer push; not a multi-GPU measurement"}
+
+
 def nominal_record(dev, dtype, steps=3):
     """The shipped architecture (actionmesh.yaml:33-43: 16 frames x 2048 tokens, width 2048, 16 heads) for a few steps, every
     algorithmic operation executed - reported beside the headline line, never as `value`."""
@@ -280,6 +344,8 @@ def main():
                          "configs[4] (use with --shape long64); GEMMs, norms and the residual stream stay bf16.  The headline "
                          "metric is bf16.")
     ap.add_argument("--graph", action="store_true", help="single GPU: the forward through a captured HIP graph (am_denoise_forward_graph)")
+    ap.add_argument("--emulate-world", type=int, default=0, metavar="P", help="single GPU only: print a PROJECTION record instead - rank 0's share of "
+                    "a step of a P-rank run timed on this device, beside the modelled xGMI time of the per-layer exchange")
     ap.add_argument("--no-nominal", action="store_true", help="skip the `nominal` sub-record (the shipped architecture, 3 steps) of the headline N=1 line")
     args = ap.parse_args()
     if args.graph:
@@ -303,6 +369,11 @@ def main():
         group = dist.group.WORLD
 
     T, N, C, H, NL, S, Dc, Din = SHAPES[args.shape]
+    if args.emulate_world:
+        assert world == 1, "--emulate-world runs on one device"
+        print(json.dumps({"metric": f"PROJECTION: rank-0 share of a {args.emulate_world}-rank denoise step ({T}f x {N}tok)", "shape": args.shape,
+                          "dtype": args.dtype, **emulate_world(args.emulate_world, args.shape, args.dtype, dev, steps=args.steps)}), flush=True)
+        return
     hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0,
               cross_attention_dim=Dc, inflated_layers=list(range(NL)))
     sd = random_state_dict(hp, seed=0)

@@ -61,6 +61,23 @@ def test_copy_engine_exchange_across_processes_on_one_device(world):
     print(out.strip().splitlines()[-2])
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_fp8_shards_across_processes_on_one_device(world):
+    """attn_dtype = fp8 under frame sharding between real processes (one device): the QUANTISED shards travel through the copy-engine
+    exchange, every rank's self-attention runs in fp8 and never in bf16 (am_attention_counters), repeated forwards are bit-identical."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _run(world, ("--same-device", "--dtype", "fp8"), tool="peer_selftest")
+    print(out.strip().splitlines()[-2])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_fp8_rccl_ranks(world):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run(world, ("--dtype", "fp8"))
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_copy_engine_exchange_on_real_ranks(world):
     if not torch.cuda.is_available() or torch.cuda.device_count() < world:

@@ -29,6 +29,8 @@ def main():
                     "am_debug_trace_begin); reports the first kernels whose output differs from forward 0")
     ap.add_argument("--va-shift", action="store_true", help="rank r allocates (and keeps) r * 96 MiB + r * 2 MiB of device memory before "
                     "anything else, so that the ranks' identical allocation sequences do NOT end up at identical virtual addresses")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the engines exchange QUANTISED shards (half the bytes) and "
+                    "run the fp8 two-pass attention; asserted through am_attention_counters")
     ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
@@ -62,7 +64,7 @@ def main():
     cos, sin = rope_tables_host(f_in, 128)
 
     plan = FrameShardPlan(T, world, rank)                       # frame sharding only: every rank exchanges with every other
-    eng = HipEngine(hp, sd, dev, B, plan.frames_local, N, S, world=world, rank=rank, attn_defer_log2=a.defer,
+    eng = HipEngine(hp, sd, dev, B, plan.frames_local, N, S, world=world, rank=rank, attn_defer_log2=a.defer, attn_dtype=a.dtype,
                     kv_factory=lambda nbytes: PeerExchange(dist.group.WORLD, plan, nbytes, dev))
     eng.set_context(plan.slice_frames(c_in.to(dev)), cos.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64),
                     sin.view(B, T, -1)[:, plan.frame_slice].reshape(-1, 64))
@@ -191,17 +193,19 @@ def main():
     # traced that to head_post consuming its cos / sin rows straight behind the load counter while another process ran bf16 GEMMs on the
     # device - csrc/am_norm.hip, DESIGN.md section 9 - and restored the exact check.)
     assert all(torch.equal(o, outs[0]) for o in outs[1:]), "forwards differ: a shard was read before it arrived / after it was overwritten"
+    n8, n16 = eng.attention_counters()
+    assert (n8 > 0 and n16 == 0) if a.dtype == "fp8" else (n8 == 0 and n16 > 0), f"--dtype {a.dtype} but launches fp8 {n8} / bf16 {n16}"
     parts = [torch.empty_like(outs[0]) for _ in range(world)]
     dist.all_gather(parts, outs[0])
     if rank == 0:
         v = torch.cat(parts, dim=1)
-        ref_eng = HipEngine(hp, sd, dev, B, T, N, S)
+        ref_eng = HipEngine(hp, sd, dev, B, T, N, S, attn_dtype=a.dtype)
         ref_eng.set_context(c_in.to(dev), cos, sin)
         ref = ref_eng.forward(x_in.to(dev), t_bt).float().cpu()
         r = float((v - ref).norm() / ref.norm())
         print(f"[peer_selftest] world {world} ({'one device' if a.same_device else 'one device per rank'}): copy-engine exchange, "
               f"sharded vs unsharded rel-L2 {r:.3e}", flush=True)
-        assert torch.isfinite(v).all() and r < 1e-2, r
+        assert torch.isfinite(v).all() and r < (3e-2 if a.dtype == "fp8" else 1e-2), r
         ref_eng.close()
         print("[peer_selftest] ok", flush=True)
     dist.barrier()

@@ -463,6 +463,19 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
 
   const int nb = tiles_m * tiles_n;
   const int bid = blockIdx.x;
+  {   // Per-XCD start skew (round 3): the first round's workgroups of XCD x start x * units * 1.5 us late (act bits 13-15, set by
+      // am_gemm_bf16), and every later round inherits the offset.  All workgroups of a round take the same time, so without it the
+      // 256 epilogues (C stores + residual loads: 64-96 MB) hit HBM in one burst while the main loops leave it idle; whole-XCD
+      // offsets spread the bursts and keep each XCD's 32 workgroups in lockstep, so they still share their A / W panels through its
+      // L2 (per-WORKGROUP offsets, tried in round 2, lost that sharing and were slower).  Same tiles, same arithmetic: bit-identical.
+      // Measured (profiles/r03h_gemm_skew.txt): qkv 0.890 -> 0.783 ms, ff1+GELU 1.396 -> 1.185, ff2 0.994 -> 0.949.
+    const int units = (p.act >> 13) & 7;
+    if (units && units < 7 && bid < 256) {
+      const unsigned long long t0 = wall_clock64();
+      const unsigned long long wait = (unsigned long long)(bid & 7) * units * 150ull;      // 100 MHz clock
+      while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+    }
+  }
   int lid;
   {
     const int xcd = bid & 7, idx = bid >> 3;
@@ -675,7 +688,7 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   const bool force_small = (args.act & 0x100) != 0;
   const bool legacy = (args.act & 0x200) != 0;
   const bool force_big = (args.act & 0x400) != 0;       // tests: the 256x256 tile whatever the grid size
-  const int abl = args.act & 0x1800;
+  const int abl = args.act & 0xF800;     // bits 11 / 12: timing ablations; bits 13-15: per-XCD start skew (experiment)
   args.act &= 0xff;
   AM_CHECK(args.act == 0 || args.act == 1, "am_gemm_bf16: unknown activation %d", args.act);
   // the 256x256 tiles need a grid that fills the 256 CUs; mid-sized problems (the context encoder's 16 x 257 rows)
@@ -683,6 +696,13 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   const bool big = !force_small && args.N >= 8 && args.M >= 1 &&
                    (force_big || (args.N >= 256 && args.M >= 1024 && (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192));
   args.act |= abl;          // kernels test `act & 0xff`; bits 11 / 12 are the store / residual timing ablations
+  if (big && (abl >> 13) == 0) {
+    // start skew per XCD in units of 1.5 us: the more rounds of workgroups a GEMM has, the better the 7-unit tail amortises
+    // (24-32 rounds: 6 us per XCD; 8 rounds: 1.5 us); act bits 13-15 = 7 turn it off (A/B runs)
+    const int rounds = (int)(((int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2)) / 256);
+    const int units = rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
+    args.act |= units << 13;
+  }
   if (big) {
     // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
     // frame): a last 256-row tile holding a few rows would cost a whole extra round of workgroups.

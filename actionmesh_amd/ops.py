@@ -87,7 +87,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.M, g.N, g.K = M, N, K
     # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings);
     # 0x200: the round-1 lockstep main loop of the 256x256 tile (same-box A/B); 0x400: the 256x256 tile at any grid size (tests)
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0x1800)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0xF800)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
     _launch(a, L.lib().am_gemm_bf16, "am_gemm_bf16", C.byref(g))

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--variants", action="store_true", help="also time the experimental schedules (AM_ATTN_ABLATIONS build)")
     ap.add_argument("--fp8", action="store_true", help="attn: the fp8 kernel too when --product-only")
     ap.add_argument("--ablate-fp8", action="store_true", help="attn: time the fp8 kernel's ablations")
+    ap.add_argument("--skew-gemm", action="store_true", help="gemm: time the per-XCD start-skew experiment (act bits 13-15)")
     ap.add_argument("--ablate-gemm", action="store_true", help="gemm: time the epilogue ablations (no C stores / no residual loads)")
     ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
     ap.add_argument("--blas", action="store_true", help="gemm: also time torch.matmul (hipBLASLt) on the same operands - the "
@@ -114,6 +115,10 @@ def main():
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
                                              force_small=small, legacy=leg), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            if a.skew_gemm:
+                for units in (7, 1, 2, 3, 4, 6):
+                    ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out, ablate=units << 13), a.reps)
+                    print(f"  gemm {name:13s} per-XCD start skew {'off' if units == 7 else f'{units * 1.5:4.1f} us x xcd'}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             if a.ablate_gemm:
                 for ab, nm in ((0x800, "no C stores"), (0x1000, "no residual loads"), (0x1800, "neither")):
                     ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out, ablate=ab), a.reps)

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
       // 256 epilogues (C stores + residual loads: 64-96 MB) hit HBM in one burst while the main loops leave it idle; whole-XCD
       // offsets spread the bursts and keep each XCD's 32 workgroups in lockstep, so they still share their A / W panels through its
       // L2 (per-WORKGROUP offsets, tried in round 2, lost that sharing and were slower).  Same tiles, same arithmetic: bit-identical.
-      // Measured (profiles/r03h_gemm_skew.txt): qkv 0.890 -> 0.783 ms, ff1+GELU 1.396 -> 1.185, ff2 0.994 -> 0.949.
+      // Measured same-box, warm (profiles/r03h_gemm_skew.txt, "off" vs best): qkv 0.828 -> 0.756 ms, ff1+GELU 1.262 -> 1.164, ff2 0.951 -> 0.936;
+      // nominal qkv 1.369 -> 1.302.
     const int units = (p.act >> 13) & 7;
     if (units && units < 7 && bid < 256) {
       const unsigned long long t0 = wall_clock64();

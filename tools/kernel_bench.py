@@ -13,7 +13,8 @@ from actionmesh_amd import ops  # noqa: E402
 
 
 def timeit(fn, reps):
-    fn()
+    for _ in range(max(3, reps)):       # warm: the first timed loop behind freshly made operands used to read ~8 % slow (clock ramp)
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

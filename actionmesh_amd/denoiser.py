@@ -62,14 +62,21 @@ class WindowCache:
     def __init__(self, generation: int, context: Optional[torch.Tensor] = None,
                  framestep: Optional[torch.Tensor] = None, n_tokens: int = 0):
         self.generation = generation
-        self._context_ref = context        # kept alive: a freed tensor's address could be handed to a different context
+        # identity of the bound context: storage address + geometry + torch's in-place version counter.  Only the STORAGE is kept
+        # alive (so the address cannot be handed to another tensor while this window is bound), not the tensor object.
+        self._context_storage = None if context is None else context.untyped_storage()
         self.context_id = None if context is None else _tensor_identity(context)
+        self._framestep_id = None if framestep is None else _tensor_identity(framestep)
+        self._framestep_storage = None if framestep is None else framestep.untyped_storage()
         self.framestep = None if framestep is None else framestep.detach().float().cpu().reshape(-1).tolist()
         self.n_tokens = n_tokens
 
     def matches(self, context: torch.Tensor, framestep: torch.Tensor, n_tokens: int) -> bool:
-        return (self.context_id == _tensor_identity(context) and self.n_tokens == n_tokens
-                and self.framestep == framestep.detach().float().cpu().reshape(-1).tolist())
+        if self.context_id != _tensor_identity(context) or self.n_tokens != n_tokens:
+            return False
+        if self._framestep_id == _tensor_identity(framestep):       # the same tensor, unmodified: no device-to-host sync per step
+            return True
+        return self.framestep == framestep.detach().float().cpu().reshape(-1).tolist()
 
 
 class HipEngine:
@@ -137,18 +144,18 @@ class HipEngine:
                     L.check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
         self._shape = None
 
-    def close(self):
+    def close(self, collective: bool = True):
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.am_destroy(self.handle)
             self.handle = None
         ex = getattr(self, "exchange", None)
         if ex is not None:
             self.exchange = None
-            ex.close()
+            ex.close(collective=collective)
 
     def __del__(self):
         try:
-            self.close()
+            self.close(collective=False)      # no collectives from a finalizer
         except Exception:
             pass
 
@@ -432,5 +439,12 @@ class HipDenoiser(nn.Module):
                 and freqs_rot.generation == self._window.generation
                 and self._window.matches(context, framestep, N)):
             freqs_rot = self.bind_window(context, framestep, N)
-        t_bt = masked_time(diffusion_time.detach().float().cpu().tolist(), mask, B, T)
+        # The C ABI takes the per-frame times from the host.  The reference sampler hands over device tensors every step
+        # (scheduler.py:151-168): the mask of a window never changes, so it is downloaded once per window and the step's time is
+        # ONE device-to-host read (the reference's own loop syncs on it as well, scheduler.py:245).
+        w = self._window
+        mkey = None if mask is None else _tensor_identity(mask)
+        if getattr(w, "_mask_key", "unset") != mkey:
+            w._mask_key, w._mask_host = mkey, (None if mask is None else mask.detach().float().cpu())
+        t_bt = masked_time(diffusion_time.detach().float().cpu().tolist(), w._mask_host, B, T)
         return self.forward_host_time(hidden_states, t_bt), freqs_rot

@@ -305,4 +305,7 @@ def nearest_neighbors(points: torch.Tensor, queries: torch.Tensor, precise: bool
     a.batch, a.precise = batch, 1 if precise else 0
     a.out_index, a.out_d2 = idx.data_ptr(), d2.data_ptr()
     _launch(queries, lib.am_nn_search, "am_nn_search", C.byref(a), ws.data_ptr(), need)
+    if bool((idx < 0).any()):
+        # the kernel's strict `<` never fires for a query whose distances are all NaN: index -1 would wrap in a later gather
+        raise ValueError("nearest_neighbors: a query has no finite distance to any point (NaN / inf coordinates in the inputs)")
     return idx, d2

@@ -239,12 +239,15 @@ class PeerExchange:
                                                torch.cuda.current_stream(self.device).cuda_stream), "am_peer_copy")
         return bool(t.item())
 
-    def close(self) -> None:
+    def close(self, collective: bool = True) -> None:
+        """Unmap the peers' buffers and free this rank's.  `collective` = True (an explicit close() on every rank) first runs a barrier:
+        nobody unmaps a buffer a peer may still push into.  A finalizer (HipEngine.__del__) must pass False: ranks are collected at
+        different times and a collective there can hang."""
         if getattr(self, "kv", None) is None:
             return
         torch.cuda.synchronize(self.device)
-        if self._group is not None:
-            dist.barrier(group=self._group)          # nobody unmaps a buffer a peer may still push into
+        if collective and self._group is not None:
+            dist.barrier(group=self._group)
         for ptr in list(self.peer_kv.values()) + list(self.peer_flags.values()):
             self.lib.am_peer_close(ptr)
         self.lib.am_peer_free(self.kv)
@@ -280,7 +283,11 @@ def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.P
             else:
                 exchange_kv(engine.kv_buffers(), plan, group)
         engine.layer_post(i)
-    return engine.end()
+    v = engine.end()
+    if exchange is not None and plan.frame_world > 1 and exchange.faulted():
+        # a flag wait gave up (a peer died or fell > 20 s behind): the attention has read stale or partial shards - never hand that on
+        raise RuntimeError("sharded_forward: the copy-engine exchange timed out waiting for a peer's K/V shard; the result is invalid")
+    return v
 
 
 def gather_frames(v_local: torch.Tensor, plan: FrameShardPlan,

@@ -107,24 +107,6 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
     for (int e = 0; e < 8; ++e) wv[e] = wt ? wt[sub * 8 + e] : 1.f;
     bf16_t* out = kind == 0 ? p.out_q : p.out_k;
     const int s_pad = kind == 0 ? p.sq_pad : p.sk_pad;
-    // The cos / sin rows of all four passes are requested up front and waited for ONCE, long before their first use.  They used to be
-    // fetched inside the pass, two global_load_dwordx4 consumed straight behind the s_waitcnt - and with ranks of ANOTHER PROCESS
-    // running bf16 GEMMs on the same device (tools/peer_selftest.py --same-device), the first use saw stale registers in lanes
-    // 48-63 (dwords 0 and 2 of the four) about once per ~6000 loads: one wrong Q / K row, a run-to-run divergence of <= 2 bf16 ulp
-    // in the model output (profiles/r03_divergence_*.txt).  The 16 lanes of a token read the same 256 bytes as the
-    // wave's other three tokens; no other load of this library is consumed that early with that address pattern.
-    f32x4_t cs_all[HP_TOK / 16], sn_all[HP_TOK / 16];
-    if (p.rope_cos) {
-#pragma unroll
-      for (int pass = 0; pass < HP_TOK / 16; ++pass) {
-        const int s = min(s0 + pass * 16 + tok_in_pass, p.seq_len - 1);
-        const int64_t frame = ((int64_t)sidx * p.seq_len + s) / p.rows_per_frame;
-        cs_all[pass] = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
-        sn_all[pass] = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
-      }
-#pragma unroll
-      for (int pass = 0; pass < HP_TOK / 16; ++pass) asm volatile("s_waitcnt vmcnt(0)" : "+v"(cs_all[pass]), "+v"(sn_all[pass]));
-    }
 #pragma unroll
     for (int pass = 0; pass < HP_TOK / 16; ++pass) {
       const int s = s0 + pass * 16 + tok_in_pass;
@@ -160,7 +142,13 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
       }
       if (p.rope_cos) {
-        const f32x4_t cs = cs_all[pass], sn = sn_all[pass];
+        const int64_t frame = row / p.rows_per_frame;
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + frame * 64 + sub * 4);
+        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + frame * 64 + sub * 4);
+        // NOTE (round 3): this file is built WITHOUT the SLP vectoriser.  Packed, the rotation below becomes
+        // v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,0], and on MI355X that instruction returns a wrong low half in lanes 48-63
+        // while another PROCESS runs bf16 GEMMs on the device (tools/repro/pk_mul_cross_process.hip) - the same-device divergence
+        // of round 2.  tests/test_host_cpu.py audits the built library for that operand-selection form.
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = v[2 * e], bb = v[2 * e + 1];

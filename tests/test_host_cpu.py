@@ -200,3 +200,37 @@ def test_attn64_register_audit(tmp_path):
     assert len(body_slots) >= 50 and min(body_slots) >= 1 and max(body_slots) <= 8, body_slots      # spread: no empty gap, no doubled one
     assert "am_attention64.audit" in open(os.path.join(csrc, "Makefile")).read()
 
+
+
+def test_no_swapped_packed_f32_in_the_built_library(tmp_path):
+    """Round 3 root cause of the same-device divergence: on MI355X `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,0]`
+    (low result = src0.lo x src1.HI) returns a wrong low half in lanes 48-63 while another process runs bf16 GEMMs on the device
+    (tools/repro/pk_mul_cross_process.hip).  hipcc's SLP vectoriser emitted it for head_post's RoPE rotation; the row-wise kernels are
+    now built without SLP.  This audit disassembles the device code of the BUILT library: no packed-FP32 instruction whose low half
+    reads the high half of an operand, anywhere; and no packed-FP32 instruction at all in the row-wise kernels."""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from actionmesh_amd import LIB_PATH
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(LIB_PATH) and os.path.exists(objdump)):
+        pytest.skip("library or llvm-objdump missing")
+    shutil.copy(LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(glob.glob(str(tmp_path / "lib.so.*gfx950")))
+    assert objs, "no gfx950 code objects in the library"
+    swapped = re.compile(r"v_pk_(mul|fma|add)_f32 .*op_sel:\[(0,1|1,0|0,1,[01]|1,0,[01]|0,0,1|1,1,0)")
+    n_pk, kernel = 0, None
+    for o in objs:
+        for line in subprocess.run([objdump, "-d", o], check=True, capture_output=True, text=True).stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+                continue
+            if "v_pk_" in line and "_f32" in line:
+                n_pk += 1
+                assert not swapped.search(line), f"{kernel}: {line.strip()}"
+                assert not any(k in (kernel or "") for k in ("head_post_kernel", "layernorm_kernel", "flow_step", "f32_to_bf16")), \
+                    f"row-wise kernel {kernel} contains a packed-FP32 instruction: {line.strip()}"
+    assert n_pk > 100, "the audit did not see the GEMM / attention kernels' packed instructions - wrong objects?"

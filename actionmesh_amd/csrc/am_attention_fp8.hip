@@ -37,6 +37,9 @@ typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+#ifndef AM_F8_PKSUM
+#define AM_F8_PKSUM 1      // row sums as packed adds: 17.55 -> 17.15 ms at the headline launch (profiles/r03k_ab.txt)
+#endif
 constexpr int HD8 = 128;
 constexpr int KT = 64;                 // keys per tile
 constexpr int STAGE_BYTES = 16384;     // K8 tile [64][128] + V8T tile [128][64]
@@ -359,7 +362,11 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bsplat[r] = P_SHIFT - m_run;
     }
+#if AM_F8_PKSUM       // the 32 row-sum adds as 16 packed adds (v_pk_add_f32, default operand selection - not the form of DESIGN.md section 9)
+    f32x2_t ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#else
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                      // four independent row-sum chains (fp32, before the rounding)
+#endif
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -368,14 +375,24 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           e[i] = (ABL & 1) ? sc[kb][4 * q4 + i] : __builtin_amdgcn_exp2f(sc[kb][4 * q4 + i]);
+#if !AM_F8_PKSUM
           ps[i] += e[i];
+#endif
         }
+#if AM_F8_PKSUM
+        ps2[0] += f32x2_t{e[0], e[1]};
+        ps2[1] += f32x2_t{e[2], e[3]};
+#endif
         int w = pf[4 * kb + q4];                               // both halves are overwritten: no zero-initialising move
         w = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w, false);
         w = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w, true);
         pf[4 * kb + q4] = w;
       }
+#if AM_F8_PKSUM
+    { const f32x2_t t = ps2[0] + ps2[1]; l_run += t[0] + t[1]; }
+#else
     l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#endif
   };
 
   // ---- schedule.  Per tile t a wave runs a softmax interval V(t) - VALU only - and a matrix interval M(t):

@@ -112,6 +112,7 @@ SYMBOLS = {
     "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),
     "am_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "am_head_post": (C.c_int, [C.POINTER(AmHeadPostArgs), _P]),
+    "am_gemm_headpost_bf16": (C.c_int, [C.POINTER(AmGemmArgs), C.POINTER(AmHeadPostArgs), _P]),
     "am_attention_bf16": (C.c_int, [C.POINTER(AmAttnArgs), _P]),
     "am_attention_quantize_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
     "am_attention_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),

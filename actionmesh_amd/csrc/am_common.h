@@ -118,6 +118,8 @@ extern std::atomic<uint64_t> g_am_scratch_generation;
 void am_trace(int tag, const void* dev_ptr, size_t bytes, void* stream);
 bool am_trace_on();
 
+int am_head_post_check(const am_headpost_args* a);      // am_norm.hip: argument validation shared with the fused QKV GEMM
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

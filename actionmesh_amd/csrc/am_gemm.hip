@@ -12,6 +12,8 @@
 // D[n][m] = W[n][k] * A[m][k] so each lane ends with 4 consecutive output
 // columns -> 16-byte LDS writes in the epilogue, which re-reads the tile
 // row-major for fully coalesced bias/GELU/residual/store.
+#include <stdlib.h>
+
 #include "am_common.h"
 
 namespace {
@@ -256,6 +258,108 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fused epilogue of the QKV (and cross-attention q) linear - north_star's "fused RMSNorm + RoPE + QKV", attention_processor.py:92-130:
+// the head split, the per-head qk-RMSNorm, the RoPE rotation and the attention operand layouts straight from the staged bf16 tile,
+// with the arithmetic of head_post_kernel (am_norm.hip) on the same bf16-rounded linear output: bit-identical Q / K / V^T, and the
+// qkv activation (R x 3C bf16: 805 MB per layer at the headline shape) is neither written nor read back.  A 256-column tile holds two
+// (head, part) slices of 128 channels:
+//   Q / K slices: the row-major reader of store_staged_tile (thread = 8 channels of one row; a row's 16 lanes are one DPP row), RMS
+//                 norm over the 16 lanes, rotation by the row's frame angle, one 16-byte store into [seq][head][s][128];
+//   V slice:      read back transposed - thread = one channel x 8 key positions (perm16 order inside every 16-key group), 8 threads
+//                 write 128 contiguous bytes of a V^T row.
+// Not handled here (am_gemm_headpost_bf16 launches am_head_post_partial behind the GEMM for them): the rows of the 128x128 tail kernel
+// and the zero fill of pad rows / columns.  Needs M % 16 == 0 and, with a V slice, seq_len % 16 == 0 (key groups must not straddle
+// tiles or sequences) - the entry point falls back to GEMM + head_post otherwise.
+__device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p, const am_headpost_args& hp, const unsigned char* stage,
+                                                           int tid, int m0, int n0) {
+  const int k16 = tid & 31, r16 = tid >> 5;
+  const int half = k16 >> 4, sub = k16 & 15;
+  {
+    const int pi = (n0 >> 7) + half;                           // (head, part) slice of this thread's 128-column half
+    const int head = pi / hp.nparts, part = pi - head * hp.nparts;
+    const int kind = (n0 + half * 128 < p.N) ? hp.kinds[part] : 3;
+    if (kind == 0 || kind == 1) {
+      const float* wt = kind == 0 ? hp.w_q : hp.w_k;
+      float wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[e] = wt ? wt[sub * 8 + e] : 1.f;
+      bf16_t* out = kind == 0 ? hp.out_q : hp.out_k;
+      const int s_pad = kind == 0 ? hp.sq_pad : hp.sk_pad;
+      const unsigned char* su = stage + r16 * 512 + ((k16 ^ (r16 >> 1)) << 4);
+      const bool odd = r16 & 1;
+#pragma unroll 2
+      for (int pass = 0; pass < 16; ++pass) {
+        const int gm = m0 + pass * 16 + r16;
+        if (gm >= p.M) continue;
+        u32x4_t u = *reinterpret_cast<const u32x4_t*>(su + pass * 8192);
+        if (odd) u = u32x4_t{u[2], u[3], u[0], u[1]};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = bflo(u[e]);
+          v[2 * e + 1] = bfhi(u[e]);
+        }
+        if (wt) {
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+          ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x128, 0xf, 0xf, false));
+          ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x124, 0xf, 0xf, false));
+          ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x122, 0xf, 0xf, false));
+          ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x121, 0xf, 0xf, false));
+          const float r = rsqrtf(ss * (1.0f / 128.0f) + hp.eps);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
+        }
+        if (hp.rope_cos) {
+          const int frame = gm / hp.rows_per_frame;
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame * 64 + sub * 4);
+          const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame * 64 + sub * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = v[2 * e], bb = v[2 * e + 1];
+            v[2 * e] = a * cs[e] + (-bb) * sn[e];
+            v[2 * e + 1] = bb * cs[e] + a * sn[e];
+          }
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        const int seq = gm / hp.seq_len, sq = gm - seq * hp.seq_len;
+        *reinterpret_cast<u32x4_t*>(out + (((int64_t)seq * hp.heads + head) * s_pad + sq) * 128 + sub * 8) = w;
+      }
+    }
+  }
+  // ---- V slice (at most one of the two halves for the q | k | v interleave): transposed read-back
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int pi = (n0 >> 7) + h2;
+    const int head = pi / hp.nparts, part = pi - head * hp.nparts;
+    if (n0 + h2 * 128 >= p.N || hp.kinds[part] != 2) continue;        // uniform over the workgroup
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+      const int pc = (lane & 7) + 8 * (it & 3);                        // chunk of 8 key POSITIONS of the tile's 256
+      const int d = ((lane >> 3) & 7) + 8 * (wave + 8 * (it >> 2));    // channel 0 .. 127
+      const int pos0 = pc * 8;
+      const int g16 = m0 + (pos0 & ~15);                               // first key (= global row) of the 16-key group
+      if (g16 >= p.M) continue;
+      const int n = h2 * 128 + d;
+      uint32_t val[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pos = pos0 + j;
+        const int m = (pos & ~15) | perm16(pos & 15);                  // position -> key row (involution)
+        val[j] = *reinterpret_cast<const uint16_t*>(stage + m * 512 + ((((n >> 2) ^ (m & 15))) << 3) + (n & 3) * 2);
+      }
+      const u32x4_t w = {val[0] | (val[1] << 16), val[2] | (val[3] << 16), val[4] | (val[5] << 16), val[6] | (val[7] << 16)};
+      const int seq = g16 / hp.seq_len, s16 = g16 - seq * hp.seq_len;
+      *reinterpret_cast<u32x4_t*>(hp.out_vt + (((int64_t)seq * hp.heads + head) * 128 + d) * hp.sk_pad + s16 + (pos0 & 15)) = w;
+    }
+  }
+}
+
 // ===========================================================================
 // v2: 256x256x64 tile, 8 waves (2 x 4, each 128 x 64), operands DMA'd straight
 // into LDS (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
@@ -458,7 +562,9 @@ constexpr int PBUF_BYTES = 4 * HT_BYTES;       // [TA0 | TA1 | TB0 | TB1] (64 Ki
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-__global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n, int m_base) {
+// HP: the fused head-split / qk-norm / RoPE / layout epilogue (store_staged_tile_headpost) instead of the C tile store
+template <bool HP>
+__global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, int tiles_m, int tiles_n, int m_base, am_headpost_args hp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int nb = tiles_m * tiles_n;
@@ -657,7 +763,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
       *reinterpret_cast<u32x2_t*>(stage + ml * 512 + u * 8) = w;
     }
   __syncthreads();
-  store_staged_tile(p, stage, tid, m0, n0);
+  if constexpr (HP) store_staged_tile_headpost(p, hp, stage, tid, m0, n0);
+  else store_staged_tile(p, stage, tid, m0, n0);
 }
 #undef PP_QUADRANT
 
@@ -680,7 +787,9 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel),
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
   });
   // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings); bit 9 (0x200) the round-1
@@ -715,8 +824,8 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
       hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
                          (hipStream_t)stream, args, tiles_m, tiles_n, 0);
     else
-      hipLaunchKernelGGL(gemm256pp_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
-                         (hipStream_t)stream, args, tiles_m, tiles_n, 0);
+      hipLaunchKernelGGL(gemm256pp_bf16_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
+                         (hipStream_t)stream, args, tiles_m, tiles_n, 0, am_headpost_args{});
     if (m_main < args.M) {
       const int tn = ceil_div(args.N, BN);
       hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
@@ -728,4 +837,56 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   }
   AM_HIP(hipGetLastError());
   return AM_OK;
+}
+
+int am_head_post_partial(const am_headpost_args* a, int s_min_last, int s_min_other, void* stream);   // am_norm.hip
+
+// nn.Linear (bias-free q | k | v projection, or the cross-attention to_q) + am_head_post in ONE launch: attention_processor.py:92-130.
+// `g` describes the linear exactly as for am_gemm_bf16 with C = hp->X / ldc = hp->ldx (the buffer the un-fused pair would go through;
+// only the rows of the 128x128 tail kernel are written to it), `hp` the head split as for am_head_post.  Falls back to the two calls
+// - same results, bit for bit - when the shape does not qualify (small grids, row maps, an activation, key groups that would straddle).
+extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_args* hp, void* stream) {
+  AM_CHECK(g && hp, "am_gemm_headpost_bf16: null argument");
+  AM_CHECK(g->C == hp->X && g->ldc == hp->ldx && (int64_t)g->M == hp->rows && g->N == hp->heads * hp->nparts * 128,
+           "am_gemm_headpost_bf16: the GEMM's output (C, ldc, M, N) must be the head split's input (X, ldx, rows, heads * nparts * 128)");
+  bool has_v = false;
+  for (int i = 0; i < hp->nparts; ++i) has_v |= hp->kinds[i] == 2;
+  const int rem = g->M % B2;
+  const bool tail_split = rem != 0 && rem <= 128 && g->M > 8 * B2;
+  const bool fuse = (g->act & 0xff) == 0 && !g->residual && !g->A2 && g->a_G == 0 && g->c_G == 0 && g->N % 256 == 0 && g->M % 16 == 0 &&
+                    g->N >= 256 && g->M >= 1024 && (int64_t)ceil_div(g->M, B2) * ceil_div(g->N, B2) >= 192 &&
+                    (!has_v || hp->seq_len % 16 == 0) && (!tail_split || rem <= hp->seq_len) && hp->rows % hp->seq_len == 0 &&
+                    !(g->act & 0x700) && getenv("ACTIONMESH_AMD_NO_FUSED_QKV") == nullptr;
+  if (!fuse) {
+    AM_TRY(am_gemm_bf16(g, stream));
+    return am_head_post(hp, stream);
+  }
+  AM_CHECK(g->K % BK == 0 && g->K1 == g->K && g->lda1 % 8 == 0 && g->ldw % 8 == 0, "am_gemm_headpost_bf16: bad GEMM operands");
+  AM_CHECK(((uintptr_t)g->A1 | (uintptr_t)g->W | (uintptr_t)g->C) % 16 == 0, "am_gemm_headpost_bf16: operands must be 16-byte aligned");
+  AM_TRY(am_head_post_check(hp));
+  AM_ONCE_PER_DEVICE({
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+  });
+  am_gemm_args args = *g;
+  args.act = 0;
+  const int m_main = tail_split ? args.M - rem : args.M;
+  const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
+  {
+    const int rounds = (int)(((int64_t)tiles_m * tiles_n) / 256);
+    const int units = rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
+    args.act |= units << 13;
+  }
+  am_gemm_args main_args = args;
+  main_args.M = m_main;                      // the fused epilogue bounds its rows by M: the main grid owns [0, m_main)
+  hipLaunchKernelGGL(gemm256pp_bf16_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES, (hipStream_t)stream, main_args, tiles_m,
+                     tiles_n, 0, *hp);
+  if (m_main < args.M) {                     // the remainder rows: plain linear into X, then the head split of exactly those rows
+    const int tn = ceil_div(args.N, BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
+  }
+  AM_HIP(hipGetLastError());
+  // tokens the fused epilogue did not produce: the tail rows (all in the last sequence) and the pad rows / columns of every sequence
+  const int s_min_last = hp->seq_len - (args.M - m_main);
+  return am_head_post_partial(hp, s_min_last, hp->seq_len, stream);
 }

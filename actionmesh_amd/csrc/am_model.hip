@@ -526,8 +526,9 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   const int64_t Rs = shared ? R / h->B : R;
   AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, Rs, C, 1e-5f, st));      // block.py:138
   TR(3, i, h->z, (size_t)Rs * C * 2);
-  AM_TRY(gemm(st, h->z, C, l.w_qkv, C, nullptr, nullptr, h->qkv, 3 * C, Rs, 3 * C, C, 0));   // :92-103
-  TR(4, i, h->qkv, (size_t)Rs * 3 * C * 2);
+  am_gemm_args gq = {};      // the q | k | v projection (:92-103), fused with the head split below (am_gemm_headpost_bf16)
+  gq.A1 = h->z; gq.lda1 = C; gq.K1 = C; gq.W = l.w_qkv; gq.ldw = C; gq.C = h->qkv; gq.ldc = 3 * C;
+  gq.M = (int)Rs; gq.N = 3 * C; gq.K = C;
   am_headpost_args hp = {};
   hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = Rs; hp.rows_per_frame = L;
   hp.heads = h->H; hp.nparts = 3; hp.kinds[0] = 0; hp.kinds[1] = 1; hp.kinds[2] = 2;
@@ -546,7 +547,13 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     hp.sq_pad = pad_to(L, 256); hp.sk_pad = pad_to(L, 64);
     hp.out_k = h->Kg; hp.out_vt = h->Vtg;
   }
-  AM_TRY(am_head_post(&hp, st));
+  if (am_trace_on()) {       // trace runs keep the two launches apart so that the linear's output can be checksummed
+    AM_TRY(am_gemm_bf16(&gq, st));
+    TR(4, i, h->qkv, (size_t)Rs * 3 * C * 2);
+    AM_TRY(am_head_post(&hp, st));
+  } else {
+    AM_TRY(am_gemm_headpost_bf16(&gq, &hp, st));
+  }
   if (am_trace_on()) {
     const size_t nseq = h->inflated(i) ? (size_t)h->B : (size_t)h->B * h->T;
     TR(5, i, h->Qb, nseq * h->H * hp.sq_pad * HD * 2);
@@ -695,14 +702,21 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       } else {
         AM_TRY(am_layernorm_bf16(hrun, h->z, l.ln_x_w, l.ln_x_b, nr, C, 1e-5f, st));
         TR(14, i, h->z, (size_t)nr * C * 2);
-        AM_TRY(gemm(st, h->z, C, l.w_xq, C, nullptr, nullptr, h->qkv, C, nr, C, C, 0));
-        TR(15, i, h->qkv, (size_t)nr * C * 2);
+        am_gemm_args gx = {};      // cross-attention to_q, fused with its head split
+        gx.A1 = h->z; gx.lda1 = C; gx.K1 = C; gx.W = l.w_xq; gx.ldw = C; gx.C = h->qkv; gx.ldc = C;
+        gx.M = (int)nr; gx.N = C; gx.K = C;
         am_headpost_args hp = {};
         hp.X = h->qkv; hp.ldx = C; hp.rows = nr; hp.seq_len = L; hp.rows_per_frame = L;
         hp.heads = h->H; hp.nparts = 1; hp.kinds[0] = 0;
         hp.w_q = l.x_nq; hp.eps = 1e-6f;
         hp.out_q = h->Qb; hp.sq_pad = pad_to(L, 256);
-        AM_TRY(am_head_post(&hp, st));
+        if (am_trace_on()) {
+          AM_TRY(am_gemm_bf16(&gx, st));
+          TR(15, i, h->qkv, (size_t)nr * C * 2);
+          AM_TRY(am_head_post(&hp, st));
+        } else {
+          AM_TRY(am_gemm_headpost_bf16(&gx, &hp, st));
+        }
         TR(16, i, h->Qb, (size_t)(b1 - b0) * h->T * h->H * hp.sq_pad * HD * 2);
         const int Spad = pad_to(h->ctxS, 64);
         am_attn_args ax = {};

@@ -87,11 +87,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 constexpr int HP_TOK = 64;
 constexpr int VT_LD = HP_TOK + 2;  // bf16 per LDS row of the transposed V tile (33 dwords: odd stride)
 
-__global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int blocks_per_seq) {
+// Partial launches (am_head_post_partial, used behind the fused QKV GEMM of am_gemm.hip): only the 64-token blocks blk0 .. of every
+// sequence are visited, and tokens s < s_min (s_min_last for the last sequence, s_min_other for the others; multiples of 16) are neither
+// read nor written - what is left are the rows the GEMM's 128x128 tail kernel produced and the zero fill of the pad rows / columns.
+__global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int blocks_per_seq, int blk0, int s_min_last, int s_min_other,
+                                                        int nseq) {
   __shared__ bf16_t vt[128 * VT_LD];
   const int tid = threadIdx.x;
-  const int sblk = blockIdx.x % blocks_per_seq;
-  const int sidx = blockIdx.x / blocks_per_seq;   // sequence index
+  const int nblk = blocks_per_seq - blk0;
+  const int sblk = blk0 + blockIdx.x % nblk;
+  const int sidx = blockIdx.x / nblk;   // sequence index
+  const int s_min = sidx == nseq - 1 ? s_min_last : s_min_other;
   const int head = blockIdx.y;
   const int part = blockIdx.z;
   const int kind = p.kinds[part];
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
 #pragma unroll
     for (int pass = 0; pass < HP_TOK / 16; ++pass) {
       const int s = s0 + pass * 16 + tok_in_pass;
+      if (s < s_min) continue;          // partial launch: this token's row was written by the fused GEMM epilogue
       if (s >= p.seq_len) {             // uniform per 16-lane group
         // K rows of the padded tail of the last key tile must be zero: the attention kernel
         // relies on score(padded key) == 0 instead of masking (am_attention.hip, tail_fix)
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
       const int tl = pass * 16 + tok_in_pass;
       const int s = s0 + tl;
       u32x4_t u = {0u, 0u, 0u, 0u};
-      if (s < p.seq_len) {
+      if (s < p.seq_len && s >= s_min) {
         const int64_t row = (int64_t)sidx * p.seq_len + s;
         u = *reinterpret_cast<const u32x4_t*>(p.X + row * p.ldx + col);
       }
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
       const uint32_t* src = reinterpret_cast<const uint32_t*>(&vt[d * VT_LD + c8]);  // 4-byte aligned (VT_LD even)
       u32x4_t w = {src[0], src[1], src[2], src[3]};
       bf16_t* dst = p.out_vt + (((int64_t)sidx * p.heads + head) * 128 + d) * p.sk_pad + s0 + c8;
-      *reinterpret_cast<u32x4_t*>(dst) = w;
+      if (s0 + c8 >= s_min) *reinterpret_cast<u32x4_t*>(dst) = w;       // s_min % 16 == 0: a whole 16-key group is in or out
     }
   }
 }
@@ -213,7 +220,19 @@ extern "C" int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w,
   return AM_OK;
 }
 
+int am_head_post_check(const am_headpost_args* a);
+
 extern "C" int am_head_post(const am_headpost_args* a, void* stream) {
+  AM_TRY(am_head_post_check(a));
+  const int nseq = (int)(a->rows / a->seq_len);
+  const int bps = ceil_div(a->seq_len, HP_TOK);
+  dim3 grid((unsigned)((int64_t)nseq * bps), a->heads, a->nparts);
+  hipLaunchKernelGGL(head_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a, bps, 0, 0, 0, nseq);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+int am_head_post_check(const am_headpost_args* a) {
   AM_CHECK(a && a->X, "am_head_post: null args");
   AM_CHECK(a->nparts >= 1 && a->nparts <= 3, "am_head_post: nparts=%d", a->nparts);
   AM_CHECK(a->rows > 0 && a->seq_len > 0 && a->rows % a->seq_len == 0, "am_head_post: rows=%lld not a multiple of seq_len=%d",
@@ -229,11 +248,19 @@ extern "C" int am_head_post(const am_headpost_args* a, void* stream) {
     if (k == 2) AM_CHECK(a->out_vt && a->sk_pad % 64 == 0 && a->sk_pad >= round_up(a->seq_len, 64) && (uintptr_t)a->out_vt % 16 == 0,
                          "am_head_post: out_vt / sk_pad=%d", a->sk_pad);
   }
+  AM_CHECK(a->heads <= 65535, "am_head_post: heads");
+  return AM_OK;
+}
+
+// Internal (am_gemm.hip, fused QKV epilogue): the tokens s >= s_min of every sequence only - see head_post_kernel.
+int am_head_post_partial(const am_headpost_args* a, int s_min_last, int s_min_other, void* stream) {
   const int nseq = (int)(a->rows / a->seq_len);
   const int bps = ceil_div(a->seq_len, HP_TOK);
-  AM_CHECK(a->heads <= 65535, "am_head_post: heads");
-  dim3 grid((unsigned)((int64_t)nseq * bps), a->heads, a->nparts);
-  hipLaunchKernelGGL(head_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a, bps);
+  const int lo = s_min_last < s_min_other ? s_min_last : s_min_other;
+  const int blk0 = lo / HP_TOK;
+  if (blk0 >= bps) return AM_OK;                         // nothing left: no tail rows and no pad rows / columns
+  dim3 grid((unsigned)((int64_t)nseq * (bps - blk0)), a->heads, a->nparts);
+  hipLaunchKernelGGL(head_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a, bps, blk0, s_min_last, s_min_other, nseq);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

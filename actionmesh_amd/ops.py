@@ -142,6 +142,51 @@ def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, r
     return out_q, out_k, out_vt
 
 
+def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, rows_per_frame: int,
+                   w_q: Optional[torch.Tensor] = None, w_k: Optional[torch.Tensor] = None,
+                   rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, eps: float = 1e-6,
+                   out_q: Optional[torch.Tensor] = None, out_k: Optional[torch.Tensor] = None,
+                   out_vt: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None):
+    """am_gemm_headpost_bf16: (a @ w.T) -> head split / qk-RMSNorm / RoPE / attention layouts in ONE launch; the arguments of `gemm`
+    (no bias, no activation) and of `head_post`.  `x` (rows, N) is the linear's output buffer the un-fused pair would use (only the
+    tile grid's remainder rows are written to it).  Returns (Q, K, Vt) like head_post."""
+    _need(a, torch.bfloat16, "a"); _need(w, torch.bfloat16, "w")
+    rows, K = a.shape
+    N = w.shape[0]
+    assert N == heads * len(kinds) * HEAD_DIM and w.shape[1] == K
+    if x is None:
+        x = torch.empty((rows, N), dtype=torch.bfloat16, device=a.device)
+    nseq = rows // seq_len
+    sq_pad, sk_pad = round_up(seq_len, 256), round_up(seq_len, 64)
+    dev = a.device
+    g = L.AmGemmArgs()
+    g.A1 = a.data_ptr(); g.lda1 = a.stride(0); g.K1 = K
+    g.W = w.data_ptr(); g.ldw = w.stride(0)
+    g.C = x.data_ptr(); g.ldc = x.stride(0)
+    g.M, g.N, g.K = rows, N, K
+    h = L.AmHeadPostArgs()
+    h.X = x.data_ptr(); h.ldx = x.stride(0)
+    h.rows = rows; h.seq_len = seq_len; h.rows_per_frame = rows_per_frame
+    h.heads = heads; h.nparts = len(kinds)
+    for i, k in enumerate(kinds):
+        h.kinds[i] = k
+    h.w_q = _p(w_q); h.w_k = _p(w_k); h.eps = eps
+    if rope is not None:
+        h.rope_cos = _need(rope[0], torch.float32, "rope_cos").data_ptr()
+        h.rope_sin = _need(rope[1], torch.float32, "rope_sin").data_ptr()
+    if 0 in kinds and out_q is None:
+        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+    if 1 in kinds and out_k is None:
+        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+    if 2 in kinds and out_vt is None:
+        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=torch.bfloat16, device=dev)
+    h.out_q = _p(out_q); h.sq_pad = out_q.shape[2] if out_q is not None else 0
+    h.out_k = _p(out_k); h.out_vt = _p(out_vt)
+    h.sk_pad = out_k.shape[2] if out_k is not None else (out_vt.shape[3] if out_vt is not None else 0)
+    _launch(a, L.lib().am_gemm_headpost_bf16, "am_gemm_headpost_bf16", C.byref(g), C.byref(h))
+    return out_q, out_k, out_vt
+
+
 STATE_LD = 132   # floats per row of a two-pass attention state: O[128], m, l, pad
 
 

@@ -219,6 +219,13 @@ typedef struct {
 } am_headpost_args;
 int am_head_post(const am_headpost_args* args, void* stream);
 
+/* The bias-free q | k | v projection (or the cross-attention to_q) AND am_head_post in one launch (north_star's "fused RMSNorm + RoPE +
+ * QKV"; attention_processor.py:92-130): the head split, qk-RMSNorm, RoPE and the operand layouts run in the GEMM's epilogue on the
+ * bf16-rounded linear output - bit-identical to am_gemm_bf16 followed by am_head_post, without the (rows x N) activation round trip.
+ * `gemm` as for am_gemm_bf16 with C = headpost->X, ldc = headpost->ldx, M = headpost->rows, N = heads * nparts * 128 (X is still needed:
+ * the remainder rows of the tile grid go through it).  Shapes that do not qualify run the two calls instead - same results. */
+int am_gemm_headpost_bf16(const am_gemm_args* gemm, const am_headpost_args* headpost, void* stream);
+
 /* F.scaled_dot_product_attention, non-causal, head_dim 128
  * (attention_processor.py:133-139).  Online-softmax flash kernel on bf16 MFMA.
  *   Q  [nseq][H][sq_pad][128]; K [chunks][nseq][H][sk_pad][128];

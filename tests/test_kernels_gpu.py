@@ -244,6 +244,59 @@ def test_head_post_cross(dev):
     assert torch.equal(vt.float(), vpad[:, :, idx].transpose(-1, -2).contiguous())
 
 
+@pytest.mark.parametrize("case", ["self_qkv_tail_and_straddle", "cross_q", "no_norm_no_rope", "misaligned_falls_back", "small_falls_back"])
+def test_gemm_headpost_fused_is_bit_identical(dev, case):
+    """am_gemm_headpost_bf16 (round 3: north_star's fused RMSNorm + RoPE + QKV - the head split in the GEMM's epilogue) against
+    am_gemm_bf16 followed by am_head_post: every byte of Q, K and V^T - including the pad rows / columns, and nothing written outside
+    (the outputs start from a sentinel).  Shapes: (a) two sequences of 8208 rows whose boundary falls inside a 256-row tile, 32
+    remainder rows behind the tile grid, q | k | v slices of two heads (tiles hold q|k, v|q, k|v); (b) the cross-attention q form
+    (one part, odd sequence length); (c) no qk-norm, no RoPE; (d, e) shapes that must take the un-fused fallback inside the entry point."""
+    from actionmesh_amd import ops
+    if case == "cross_q":
+        heads, kinds, T, Lr, nseq_frames = 4, (0,), 48, 513, True
+    elif case == "misaligned_falls_back":
+        heads, kinds, T, Lr, nseq_frames = 2, (0, 1, 2), 15, 513, False          # seq_len = 7695: key groups would straddle sequences
+    elif case == "small_falls_back":
+        heads, kinds, T, Lr, nseq_frames = 2, (0, 1, 2), 4, 512, False
+    else:
+        heads, kinds, T, Lr, nseq_frames = 2, (0, 1, 2), 16, 513, False
+    Cw = 256
+    B = 1 if nseq_frames else 2
+    seq_len = Lr if nseq_frames else T * Lr
+    rows = B * T * Lr
+    N = heads * len(kinds) * 128
+    a = _randn((rows, Cw), 1, dev).to(torch.bfloat16)
+    w = _randn((N, Cw), 2, dev, Cw ** -0.5).to(torch.bfloat16)
+    norm = case != "no_norm_no_rope"
+    wq = (_randn((128,), 3, dev) * 0.2 + 1.0) if norm else None
+    wk = (_randn((128,), 4, dev) * 0.2 + 1.0) if norm else None
+    rope = None
+    if norm and not nseq_frames:
+        ang = torch.arange(B * T, device=dev)[:, None].float() * (10000.0 ** (-torch.arange(64, device=dev).float() * 2 / 128))[None]
+        rope = (torch.cos(ang).contiguous(), torch.sin(ang).contiguous())
+    nseq = rows // seq_len
+    sq_pad, sk_pad = ops.round_up(seq_len, 256), ops.round_up(seq_len, 64)
+
+    def outs():
+        s_ = torch.full((1,), -3.0, dtype=torch.bfloat16, device=dev)
+        return (s_.expand(nseq, heads, sq_pad, 128).contiguous() if 0 in kinds else None,
+                s_.expand(nseq, heads, sk_pad, 128).contiguous() if 1 in kinds else None,
+                s_.expand(nseq, heads, 128, sk_pad).contiguous() if 2 in kinds else None)
+
+    q0, k0, v0 = outs()
+    x = ops.gemm(a, w)
+    ops.head_post(x, heads, kinds, seq_len, Lr, w_q=wq, w_k=wk, rope=rope, out_q=q0, out_k=k0, out_vt=v0)
+    q1, k1, v1 = outs()
+    ops.gemm_head_post(a, w, heads, kinds, seq_len, Lr, w_q=wq, w_k=wk, rope=rope, out_q=q1, out_k=k1, out_vt=v1)
+    torch.cuda.synchronize()
+    for nm, r, f in (("Q", q0, q1), ("K", k0, k1), ("V^T", v0, v1)):
+        if r is not None:
+            bad = (r.view(torch.int16) != f.view(torch.int16))
+            assert not bool(bad.any()), f"{case}: {nm} differs in {int(bad.sum())} elements, first at {bad.nonzero()[0].tolist()}"
+    if 1 in kinds and sk_pad > seq_len:
+        assert bool((k1[:, :, seq_len:] == 0).all()) and bool((v1[..., seq_len:] == 0).all()), "pad rows / columns must be zero"
+
+
 # ------------------------------------------------------------------------------------------
 def _layout(q, k, v, nchunks=1):
     """(nseq,H,S,128) tensors -> padded kernel operands; keys split in `nchunks` equal chunks."""

@@ -101,6 +101,23 @@ def main():
                 continue
             print(f"cross-attn BT={BT} H={H} L={L} S={S} variant={d:3d} ({nm:8s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         del Q, K, Vt, out
+    if "fused" in only:          # the QKV linear + head split: one launch (am_gemm_headpost_bf16) vs two
+        L_ = N + 1
+        z = rnd(R, C); wqkv = rnd(3 * C, C)
+        nq = torch.ones(128, device=dev); nk = torch.ones(128, device=dev)
+        ang = torch.arange(2 * T, device=dev)[:, None].float() * (10000.0 ** (-torch.arange(64, device=dev).float() * 2 / 128))[None]
+        rope = (torch.cos(ang).contiguous(), torch.sin(ang).contiguous())
+        x = torch.empty((R, 3 * C), dtype=torch.bfloat16, device=dev)
+        q_, k_, v_ = ops.head_post(ops.gemm(z, wqkv, out=x), H, (0, 1, 2), T * L_, L_, w_q=nq, w_k=nk, rope=rope)
+        two = timeit(lambda: ops.head_post(ops.gemm(z, wqkv, out=x), H, (0, 1, 2), T * L_, L_, w_q=nq, w_k=nk, rope=rope, out_q=q_, out_k=k_, out_vt=v_), a.reps)
+        one = timeit(lambda: ops.gemm_head_post(z, wqkv, H, (0, 1, 2), T * L_, L_, w_q=nq, w_k=nk, rope=rope, out_q=q_, out_k=k_, out_vt=v_, x=x), a.reps)
+        print(f"qkv linear + head split  R={R} 3C={3 * C}: two launches {two:8.3f} ms, fused {one:8.3f} ms")
+        wxq = rnd(C, C)
+        xq = torch.empty((R, C), dtype=torch.bfloat16, device=dev)
+        qx, _, _ = ops.head_post(ops.gemm(z, wxq, out=xq), H, (0,), L_, L_, w_q=nq)
+        two = timeit(lambda: ops.head_post(ops.gemm(z, wxq, out=xq), H, (0,), L_, L_, w_q=nq, out_q=qx), a.reps)
+        one = timeit(lambda: ops.gemm_head_post(z, wxq, H, (0,), L_, L_, w_q=nq, out_q=qx, x=xq), a.reps)
+        print(f"cross to_q + head split  R={R} C={C}: two launches {two:8.3f} ms, fused {one:8.3f} ms")
     if "gemm" in only:
         F_ = 4 * C
         for name, Nn, Kk, kw in (("qkv", 3 * C, C, {}), ("attn-out+res", C, C, {"res": True, "bias": True}),

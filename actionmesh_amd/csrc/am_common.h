@@ -63,6 +63,16 @@ __device__ inline uint32_t pack_bf2(float lo, float hi) {
 __device__ inline float bflo(uint32_t w) { return bf2f((bf16_t)(w & 0xffffu)); }
 __device__ inline float bfhi(uint32_t w) { return bf2f((bf16_t)(w >> 16)); }
 
+// RoPE rotation of one channel pair (rotary_embedding.py:116-122: x cos + rotate(x) sin in fp32), with the roundings spelled out so
+// that every kernel that rotates (head_post_kernel, the fused QKV epilogue of am_gemm.hip) produces the same bits whatever the
+// compiler would have contracted: x0' = fma(x0, c, -(x1 s)), x1' = fma(x0, s, x1 c).
+__device__ inline void rope_rotate(float& x0, float& x1, float c, float s) {
+  const float a = x0, b = x1;
+  const float bs = b * s, bc = b * c;
+  x0 = __builtin_fmaf(a, c, -bs);
+  x1 = __builtin_fmaf(a, s, bc);
+}
+
 // erf-GELU (F.gelu(approximate="none")).  erfc(|x|/sqrt2) by Abramowitz-Stegun 7.1.26 on the hardware
 // rcp / exp2: |error| <= 3.3e-7 absolute, <= 1.7e-4 relative for |gelu| > 1e-3 - an order of magnitude
 // below the bf16 rounding applied to the result - at ~14 instructions instead of ~50 for libm erff

@@ -303,25 +303,21 @@ __device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p
         if (wt) {
           float ss = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+          for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[e], v[e], ss);      // one rounding per term, in both kernels that normalise
           ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x128, 0xf, 0xf, false));
           ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x124, 0xf, 0xf, false));
           ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x122, 0xf, 0xf, false));
           ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x121, 0xf, 0xf, false));
           const float r = rsqrtf(ss * (1.0f / 128.0f) + hp.eps);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] * r) * wv[e];
         }
         if (hp.rope_cos) {
           const int frame = gm / hp.rows_per_frame;
           const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame * 64 + sub * 4);
           const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame * 64 + sub * 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a = v[2 * e], bb = v[2 * e + 1];
-            v[2 * e] = a * cs[e] + (-bb) * sn[e];
-            v[2 * e + 1] = bb * cs[e] + a * sn[e];
-          }
+          for (int e = 0; e < 4; ++e) rope_rotate(v[2 * e], v[2 * e + 1], cs[e], sn[e]);    // rotary_embedding.py:116-122
         }
         u32x4_t w;
 #pragma unroll

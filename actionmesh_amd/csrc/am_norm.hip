@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
       if (wt) {
         float ss = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        for (int e = 0; e < 8; ++e) ss = __builtin_fmaf(v[e], v[e], ss);      // one rounding per term, in both kernels that normalise
         // butterfly over the 16 lanes of a token as DPP row rotations: ss is (16 / step)-periodic after each step, so rotating by
         // `step` meets the same partner value as lane ^ step - bit-identical to the __shfl_xor form, no LDS-crossbar round trip
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x128, 0xf, 0xf, false));
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0x121, 0xf, 0xf, false));
         const float r = rsqrtf(ss * (1.0f / 128.0f) + p.eps);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * r * wv[e];
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] * r) * wv[e];
       }
       if (p.rope_cos) {
         const int64_t frame = row / p.rows_per_frame;
@@ -157,12 +157,7 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
         // while another PROCESS runs bf16 GEMMs on the device (tools/repro/pk_mul_cross_process.hip) - the same-device divergence
         // of round 2.  tests/test_host_cpu.py audits the built library for that operand-selection form.
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = v[2 * e], bb = v[2 * e + 1];
-          // out = x*cos + rotate(x)*sin, rotate = [-x_imag, x_real] (rotary_embedding.py:116-122)
-          v[2 * e] = a * cs[e] + (-bb) * sn[e];
-          v[2 * e + 1] = bb * cs[e] + a * sn[e];
-        }
+        for (int e = 0; e < 4; ++e) rope_rotate(v[2 * e], v[2 * e + 1], cs[e], sn[e]);    // rotary_embedding.py:116-122
       }
       u32x4_t w;
 #pragma unroll

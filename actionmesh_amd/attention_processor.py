@@ -121,9 +121,9 @@ class HipAttentionProcessor:
                     raise NotImplementedError("HipAttentionProcessor: encoder_hidden_states on a self-attention module")
                 seq = n_frames * Ltok if inflate_self_attention else Ltok      # flat_batch_to_flat_seq, tensor_ops.py:89-100
                 rope = None if freqs_rot is None else self._rope_tables(freqs_rot, BT, Ltok, dev)
-                qkv = ops.gemm(x, p["w_qkv"])                                                   # :92-103
-                q, k, vt = ops.head_post(qkv, H, (0, 1, 2), seq, Ltok, w_q=p["n_q"], w_k=p["n_k"], rope=rope,
-                                         eps=float(getattr(attn.norm_q, "eps", 1e-6) or 1e-6))  # :106-130
+                # :92-103 + :106-130 in one launch (am_gemm_headpost_bf16; small shapes run the two kernels inside the entry point)
+                q, k, vt = ops.gemm_head_post(x, p["w_qkv"], H, (0, 1, 2), seq, Ltok, w_q=p["n_q"], w_k=p["n_k"], rope=rope,
+                                              eps=float(getattr(attn.norm_q, "eps", 1e-6) or 1e-6))
                 o = ops.attention(q, k, vt, seq, seq)                                           # :133-139
             else:
                 ctx = encoder_hidden_states
@@ -132,8 +132,8 @@ class HipAttentionProcessor:
                 S, Dc = ctx.shape[1], ctx.shape[2]
                 c = ctx.detach().reshape(BT * S, Dc)
                 c = ops.f32_to_bf16(c.contiguous()) if c.dtype == torch.float32 else c.to(torch.bfloat16).contiguous()
-                qx = ops.gemm(x, p["w_q"])
-                q, _, _ = ops.head_post(qx, H, (0,), Ltok, Ltok, w_q=p["n_q"], eps=float(getattr(attn.norm_q, "eps", 1e-6) or 1e-6))
+                q, _, _ = ops.gemm_head_post(x, p["w_q"], H, (0,), Ltok, Ltok, w_q=p["n_q"],
+                                             eps=float(getattr(attn.norm_q, "eps", 1e-6) or 1e-6))
                 kv = ops.gemm(c, p["w_kv"])                                                     # :102-103, 111-115
                 _, k, vt = ops.head_post(kv, H, (1, 2), S, S, w_k=p["n_k"], eps=float(getattr(attn.norm_k, "eps", 1e-6) or 1e-6))
                 o = ops.attention(q, k, vt, Ltok, S)

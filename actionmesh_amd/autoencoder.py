@@ -129,8 +129,7 @@ class HipAutoencoder:
     def _self_block(self, i: int, h: torch.Tensor, B: int, T: int, L: int, rope) -> torch.Tensor:
         w, p = self._w, f"blocks.{i}."
         z = ops.layernorm(h, w[p + "norm_s_attn.w"], w[p + "norm_s_attn.b"])
-        qkv = ops.gemm(z, w[p + "qkv"])
-        Q, K, Vt = ops.head_post(qkv, self.heads, (0, 1, 2), T * L, L, rope=rope)        # no qk-norm, temporal RoPE
+        Q, K, Vt = ops.gemm_head_post(z, w[p + "qkv"], self.heads, (0, 1, 2), T * L, L, rope=rope)   # fused linear + head split: no qk-norm, temporal RoPE
         a = ops.attention(Q, K, Vt, T * L, T * L)
         h = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"], residual=h)
         return self._ff(p, h)
@@ -141,8 +140,7 @@ class HipAutoencoder:
         kv = ops.gemm(e, w[p + "kv"])
         _, K, Vt = ops.head_post(kv, self.heads, (1, 2), S, S)
         z = ops.layernorm(qh, w[p + "norm_x_attn.w"], w[p + "norm_x_attn.b"])
-        q = ops.gemm(z, w[p + "q"])
-        Q, _, _ = ops.head_post(q, self.heads, (0,), V, V)
+        Q, _, _ = ops.gemm_head_post(z, w[p + "q"], self.heads, (0,), V, V)
         a = ops.attention(Q, K, Vt, V, S)
         h = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"], residual=qh)
         return self._ff(p, h)

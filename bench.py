@@ -116,7 +116,7 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
     attn = ops.attention_fp8 if dtype == "fp8" else ops.attention
     peak = PEAK_FP8_TFLOPS if dtype == "fp8" else PEAK_BF16_TFLOPS
 
-    def sample(qscale):
+    def sample(qscale, K=K, Vt=Vt):
         Q = (Qf * qscale).to(torch.bfloat16)          # fp8: one launch = quantise pass + attention kernel, as the model runs a layer
         attn(Q, K, Vt, Sq, Sq, out=out, nchunks=fw)
         torch.cuda.synchronize()
@@ -134,6 +134,10 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
                 "fallback_workgroups_per_launch": (ops.attention_fallback_count() - f0) / reps}
 
     plain, peaky = sample(1.0), sample(4.0)
+    # the same launch on all-zero operands: nothing toggles, the chip keeps its full clock, and what is left is the instruction
+    # stream's own rate (= the MFMA-busy fraction of the counters); the distance from `plain` to it is the power budget
+    # (tools/clock_probe.py), not the schedule.  Diagnostic only: never `achieved`.
+    zeros = sample(0.0, torch.zeros_like(K), torch.zeros_like(Vt)) if dtype == "bf16" else None      # (fp8: no scale for an all-zero head)
     # HBM traffic per launch: rocprofv3 --pmc passes of tools/gpu_profile.sh on the SAME launch shape; the committed summary
     # is quoted only when it names the kernel sources it was measured on and they are the ones built now - otherwise null.
     traffic, traffic_src = None, None
@@ -151,7 +155,8 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
             "achieved": plain["achieved"], "peak": peak, "unit": "TFLOP/s",
             "frac": plain["frac"], "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": plain["launch_ms"], "flops_per_launch": flops,
-            "samples": {"plain (scores ~ N(0,1))": plain, "peaky (Q x4: scores ~ N(0,16^2))": peaky}}
+            "samples": {"plain (scores ~ N(0,1))": plain, "peaky (Q x4: scores ~ N(0,16^2))": peaky,
+                        "zero operands (diagnostic: same launch, nothing toggles - the schedule's rate at the full clock)": zeros}}
 
 
 def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):

@@ -11,6 +11,7 @@ from .image_encoder import HipImageEncoder  # noqa: F401
 from .denoiser import HipDenoiser, HipEngine, WindowCache  # noqa: F401
 from .mesh_io import create_animated_glb, load_glb, save_deformation, save_meshes  # noqa: F401
 from . import actionbench  # noqa: F401
+from .dropin import install, uninstall  # noqa: F401
 from .scheduler import ClassifierFreeGuidance, HipSchedulerFlow  # noqa: F401
 from .sharding import FrameShardPlan  # noqa: F401
 from .windows import LatentBank, chunk_from, denoise_window, generate_3d_latents, generate_vertex_animation  # noqa: F401
@@ -18,4 +19,4 @@ from .windows import LatentBank, chunk_from, denoise_window, generate_3d_latents
 __all__ = ["HipAutoencoder", "HipImageEncoder", "HipDenoiser", "HipEngine", "HipSchedulerFlow", "ClassifierFreeGuidance",
            "FrameShardPlan", "WindowCache", "HipLibraryMissing", "LIB_PATH",
            "LatentBank", "chunk_from", "denoise_window", "generate_3d_latents", "generate_vertex_animation", "save_deformation",
-           "save_meshes", "create_animated_glb", "load_glb", "actionbench"]
+           "save_meshes", "create_animated_glb", "load_glb", "actionbench", "install", "uninstall"]

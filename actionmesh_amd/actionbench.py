@@ -124,8 +124,9 @@ def chamfer_distance_sq(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """pytorch3d.loss.chamfer_distance(x, y, batch_reduction=None)[0]: per batch entry, mean_i min_j |x_i - y_j|^2 +
     mean_j min_i |y_j - x_i|^2; differentiable w.r.t. both clouds through the matched pairs."""
     with torch.no_grad():
-        ixy, _ = ops.nearest_neighbors(y.detach().contiguous(), x.detach().contiguous(), precise=False)
-        iyx, _ = ops.nearest_neighbors(x.detach().contiguous(), y.detach().contiguous(), precise=False)
+        ixy, _ = ops.nearest_neighbors(y.detach().contiguous(), x.detach().contiguous(), precise=False, check=False)
+        iyx, _ = ops.nearest_neighbors(x.detach().contiguous(), y.detach().contiguous(), precise=False, check=False)
+        ops.nn_indices_valid(ixy, iyx)        # one host read for both searches (the ICP loop reads its loss once per iteration anyway)
     gx = torch.gather(y, 1, ixy.long()[..., None].expand(-1, -1, 3))
     gy = torch.gather(x, 1, iyx.long()[..., None].expand(-1, -1, 3))
     return (x - gx).pow(2).sum(-1).mean(1) + (y - gy).pow(2).sum(-1).mean(1)

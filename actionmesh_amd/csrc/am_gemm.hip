@@ -13,6 +13,7 @@
 // columns -> 16-byte LDS writes in the epilogue, which re-reads the tile
 // row-major for fully coalesced bias/GELU/residual/store.
 #include <stdlib.h>
+#include <string.h>
 
 #include "am_common.h"
 
@@ -766,6 +767,26 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
 
 }  // namespace
 
+// Per-XCD start skew of the big GEMMs: how many 1.5 us units XCD x's first round starts late (kernel: act bits 13-15).  The
+// kernel's `blockIdx & 7 == XCD` mapping, the 100 MHz wall clock and the 256-workgroup first round describe ONE part in ONE
+// partition mode: an MI355X (gfx950) in SPX mode - 256 CUs visible as one device.  Anywhere else (CPX / DPX partitions, CU-masked
+// streams shrink multiProcessorCount; other parts) the skew would be pure added latency, so it is 0 there; the environment
+// variable ACTIONMESH_AMD_GEMM_SKEW=0 turns it off on the MI355X as well.
+static int gemm_skew_units(int rounds) {
+  static int enabled[64];           // 0 unknown, 1 on, 2 off
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (enabled[dev] == 0) {
+    hipDeviceProp_t pr;
+    bool on = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256 && strncmp(pr.gcnArchName, "gfx950", 6) == 0;
+    const char* e = getenv("ACTIONMESH_AMD_GEMM_SKEW");
+    if (e && e[0] == '0') on = false;
+    enabled[dev] = on ? 1 : 2;
+  }
+  if (enabled[dev] != 1) return 0;
+  return rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
+}
+
 extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_gemm_bf16: null args");
   AM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "am_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -806,8 +827,7 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
     // start skew per XCD in units of 1.5 us: the more rounds of workgroups a GEMM has, the better the 7-unit tail amortises
     // (24-32 rounds: 6 us per XCD; 8 rounds: 1.5 us); act bits 13-15 = 7 turn it off (A/B runs)
     const int rounds = (int)(((int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2)) / 256);
-    const int units = rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
-    args.act |= units << 13;
+    args.act |= gemm_skew_units(rounds) << 13;
   }
   if (big) {
     // M = B*T*(N+1) is 256*k + a small remainder for every reference shape (the +1 time token per
@@ -849,7 +869,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   for (int i = 0; i < hp->nparts; ++i) has_v |= hp->kinds[i] == 2;
   const int rem = g->M % B2;
   const bool tail_split = rem != 0 && rem <= 128 && g->M > 8 * B2;
-  const bool fuse = (g->act & 0xff) == 0 && !g->residual && !g->A2 && g->a_G == 0 && g->c_G == 0 && g->N % 256 == 0 && g->M % 16 == 0 &&
+  const bool fuse = (g->act & 0xff) == 0 && !g->residual && !g->bias && !g->A2 && g->a_G == 0 && g->c_G == 0 && g->N % 256 == 0 && g->M % 16 == 0 &&
                     g->N >= 256 && g->M >= 1024 && (int64_t)ceil_div(g->M, B2) * ceil_div(g->N, B2) >= 192 &&
                     (!has_v || hp->seq_len % 16 == 0) && (!tail_split || rem <= hp->seq_len) && hp->rows % hp->seq_len == 0 &&
                     !(g->act & 0x700) && getenv("ACTIONMESH_AMD_NO_FUSED_QKV") == nullptr;
@@ -870,8 +890,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
   {
     const int rounds = (int)(((int64_t)tiles_m * tiles_n) / 256);
-    const int units = rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
-    args.act |= units << 13;
+    args.act |= gemm_skew_units(rounds) << 13;
   }
   am_gemm_args main_args = args;
   main_args.M = m_main;                      // the fused epilogue bounds its rows by M: the main grid owns [0, m_main)

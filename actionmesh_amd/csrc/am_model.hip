@@ -640,9 +640,17 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     at.rows = 1; at.state_mode = 2; at.state = h->attn_state;
     at.nchunks = h->P - 1; at.chunk_first = (h->rank + 1) % h->P; at.chunk_total = h->P;
     if (am_trace_on()) {
+      // the shards the attention really reads: an fp8 handle with P > 1 gathers QUANTISED shards in K8 / Vt8 (Kg / Vtg then hold one
+      // chunk only - ensure_kv - so walking P chunks of them would read out of bounds)
+      const bool fp8_sharded = h->cfg.attn_fp8 && h->P > 1;
       for (int c = 0; c < h->P; ++c) {
-        TR(8, i, h->Kg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
-        TR(8, i, h->Vtg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
+        if (fp8_sharded) {
+          TR(8, i, h->K8 + (size_t)c * h->chunk_stride8, h->chunk_elems);
+          TR(8, i, h->Vt8 + (size_t)c * h->chunk_stride8, h->chunk_elems);
+        } else {
+          TR(8, i, h->Kg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
+          TR(8, i, h->Vtg + (size_t)c * h->chunk_stride, h->chunk_elems * 2);
+        }
       }
       TR(9, i, h->Qb, (size_t)at.nseq * at.heads * at.sq_pad * HD * 2);
       TR(26, i, h->attn_state, (size_t)at.nseq * at.heads * at.sq_pad * 132 * 4);

@@ -429,7 +429,18 @@ class HipDenoiser(nn.Module):
             v_local = e.forward(x_local, t_local)
         else:
             v_local = sharded_forward(e, plan, self._frame_group(plan), x_local, t_local, exchange=getattr(e, "exchange", None))
-        return gather_frames(v_local, plan, self.process_group)
+        self._gather_out = gather_frames(v_local, plan, self.process_group, out=getattr(self, "_gather_out", None))
+        return self._gather_out[1]
+
+    def check_exchange(self, block: bool = True) -> None:
+        """Raise if a flag wait of the copy-engine exchange gave up (a peer died or fell > 20 s behind: the attention then read
+        stale or partial shards).  `block=False` looks at the copy of the fault word the LAST forward left in pinned host memory
+        (no device sync: HipSchedulerFlow polls it once per step, a step late at worst - the word is sticky); `block=True`
+        synchronises the stream first (the end of a sampling loop, and every forward of the reference-driven S2 seam, whose own
+        loop syncs once per step anyway, scheduler.py:245)."""
+        ex = getattr(self._engine, "exchange", None) if self._engine is not None else None
+        if ex is not None and ex.faulted(block=block):
+            raise RuntimeError("HipDenoiser: the copy-engine exchange timed out waiting for a peer's K/V shard; the result is invalid")
 
     def forward(self, hidden_states: torch.Tensor, context: torch.Tensor, framestep: torch.Tensor,
                 diffusion_time: torch.Tensor, mask: Optional[torch.Tensor] = None,
@@ -446,5 +457,12 @@ class HipDenoiser(nn.Module):
         mkey = None if mask is None else _tensor_identity(mask)
         if getattr(w, "_mask_key", "unset") != mkey:
             w._mask_key, w._mask_host = mkey, (None if mask is None else mask.detach().float().cpu())
+            # keep the STORAGE alive while its address is part of the key: the caching allocator could otherwise hand the same address
+            # (with _version 0) to another mask of the same shape and the stale host copy would match it
+            w._mask_storage = None if mask is None else mask.untyped_storage()
         t_bt = masked_time(diffusion_time.detach().float().cpu().tolist(), w._mask_host, B, T)
-        return self.forward_host_time(hidden_states, t_bt), freqs_rot
+        v = self.forward_host_time(hidden_states, t_bt)
+        self.check_exchange(block=True)
+        if self.process_group is not None:
+            v = v.clone()          # the sharded path hands out its re-used gather buffer; the reference sampler may keep several results
+        return v, freqs_rot

@@ -323,11 +323,15 @@ def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], d
                                  un, T, N, D)
 
 
-def nearest_neighbors(points: torch.Tensor, queries: torch.Tensor, precise: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+def nearest_neighbors(points: torch.Tensor, queries: torch.Tensor, precise: bool = True,
+                      check: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """am_nn_search: for every query its nearest point (exact, brute force).  points (P, 3) or (B, P, 3) fp32, queries
     (Q, 3) or (B, Q, 3) fp32 (a 2-D operand beside a 3-D one is shared by the batch).  Returns (index int32, SQUARED
     distance: float64 when `precise` - the KD-tree arithmetic of actionbench/chamfer.py - else float32), shaped like the
-    queries minus the coordinate axis."""
+    queries minus the coordinate axis.
+    `check` (default): one device-to-host read behind the search that turns "no finite distance" (index -1) into an error.
+    Callers inside a loop of searches (the ICP: 4800 of them) pass check=False and validate once per batch instead
+    (`nn_indices_valid`), so the stream is not serialised per search."""
     _need(points, torch.float32, "points"); _need(queries, torch.float32, "queries")
     if points.shape[-1] != 3 or queries.shape[-1] != 3 or points.dim() not in (2, 3) or queries.dim() not in (2, 3):
         raise ValueError(f"nearest_neighbors: expected (..., n, 3) operands, got {tuple(points.shape)} / {tuple(queries.shape)}")
@@ -350,7 +354,17 @@ def nearest_neighbors(points: torch.Tensor, queries: torch.Tensor, precise: bool
     a.batch, a.precise = batch, 1 if precise else 0
     a.out_index, a.out_d2 = idx.data_ptr(), d2.data_ptr()
     _launch(queries, lib.am_nn_search, "am_nn_search", C.byref(a), ws.data_ptr(), need)
-    if bool((idx < 0).any()):
+    if check and bool((idx < 0).any()):
         # the kernel's strict `<` never fires for a query whose distances are all NaN: index -1 would wrap in a later gather
         raise ValueError("nearest_neighbors: a query has no finite distance to any point (NaN / inf coordinates in the inputs)")
     return idx, d2
+
+
+def nn_indices_valid(*indices: torch.Tensor) -> None:
+    """The deferred form of nearest_neighbors' check: ONE device-to-host read for any number of index tensors."""
+    bad = None
+    for i in indices:
+        b = (i < 0).any()
+        bad = b if bad is None else (bad | b)
+    if bad is not None and bool(bad):
+        raise ValueError("nearest_neighbors: a query has no finite distance to any point (NaN / inf coordinates in the inputs)")

@@ -163,13 +163,16 @@ class HipSchedulerFlow:
                     vs = []
                     for b in range(nb):
                         diffusion_model.bind_window(ctx_b[b:b + 1], fs_b[b:b + 1], N, ctx_zero=zero[b:b + 1])
-                        vs.append(diffusion_model.forward_host_time(latents, [t * k for k in keep[b]]))
+                        vb = diffusion_model.forward_host_time(latents, [t * k for k in keep[b]])
+                        # a sharded denoiser hands out its (re-used) gather buffer: keep a copy before the next branch overwrites it
+                        vs.append(vb.clone() if diffusion_model.process_group is not None else vb)
                     v = torch.cat(vs, dim=0)
                 else:
                     t_bt = [t * k for row in keep for k in row]              # temporal_denoiser.py:209-212
                     x_in = latents.expand(nb, T, N, D).contiguous()
                     v = diffusion_model.forward_host_time(x_in, t_bt)
                 ops.flow_step(v, latents[0], scales, dt, self.is_additive, unobserved)
+            diffusion_model.check_exchange(block=False)      # copy-engine exchange: last step's fault word, no device sync
             yield latents, timesteps[i]
 
     @torch.no_grad()
@@ -184,4 +187,6 @@ class HipSchedulerFlow:
             latents = sample
             if step_callback is not None:
                 step_callback(step_idx + 1, total)
+        if isinstance(diffusion_model, HipDenoiser):
+            diffusion_model.check_exchange(block=True)       # the blocking verdict before the latents are handed on
         return latents

@@ -159,7 +159,29 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
                         "zero operands (diagnostic: same launch, nothing toggles - the schedule's rate at the full clock)": zeros}}
 
 
-def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
+def reference_full_shape(shape):
+    """A MEASUREMENT (not a fit) of the reference's own unmodified modules at the full benchmark shape: the forward that produced
+    tests/golden/full_<shape>.npz in the build container (oracle/make_golden_baseline.py make_full: ActionMeshDenoiser.forward, fp32,
+    CPU, B = 2 CFG batch) stored its wall time and thread count in the fixture.  Another host than this box's - which is why it is
+    reported beside the fit, not instead of it."""
+    path = os.path.join(ROOT, "tests", "golden", f"full_{shape}.npz")
+    if not os.path.exists(path):
+        return None
+    import numpy as np
+    g = np.load(path)
+    if "fwd_seconds_fp32" not in g.files:
+        return None
+    rec = {"seconds": round(float(g["fwd_seconds_fp32"]), 1), "threads": int(g["host_threads"]) if "host_threads" in g.files else None,
+           "source": f"tests/golden/full_{shape}.npz",
+           "what": "ONE fp32 forward (B=2) of the reference's own modules (+ diffusers shim) at this exact shape, timed when the parity "
+                   "fixture was generated in the build container (not on this box)"}
+    if "fwd_seconds_autocast" in g.files:
+        rec["seconds_autocast_bf16"] = round(float(g["fwd_seconds_autocast"]), 1)
+    rec["value"] = round(1.0 / float(g["fwd_seconds_fp32"]), 6)
+    return rec
+
+
+def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full, deep=False, shape=None):
     """The reference CPU path (fp32 - the reference's cuda autocast is inert on CPU) timed on this box's host cores on a
     bounded sample and extrapolated to the full step the way SURVEY 8(d) prescribes: full 21-layer forwards at
     N in {256, 512, 1024} latent tokens per frame at the workload's own T = 16 and C (TL = T (N + 1) = 4112 / 8208 / 16400 tokens per
@@ -202,7 +224,7 @@ def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
     Ts = 16          # the workload's own frame count: TL = 4112, 8208, 16400 - the fit is evaluated x4 beyond the largest sample
     pts = []
     with torch.no_grad():
-        for Ns in (64, 256, 512, 1024):          # 64: untimed warm-up of the thread pool / allocator
+        for Ns in (64, 256, 512, 1024) + ((2048,) if deep else ()):          # 64: untimed warm-up of the thread pool / allocator
             g = torch.Generator().manual_seed(0)
             x = torch.randn(2, Ts, Ns, hp["in_channels"], generator=g)
             c = torch.randn(2, Ts, S, hp["cross_attention_dim"], generator=g)
@@ -228,12 +250,15 @@ def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full):
     flat = sum(p[2] for p in pts) / sum(p[1] for p in pts)
     resid = max(abs(qa * p[0] ** 2 + qb * p[0] - p[1]) / p[1] for p in pts)      # worst relative misfit at the samples
     quad_share = qa * TLf * TLf / sec_full
+    ns_txt = ", ".join(str(p[0] // Ts - 1) for p in pts)
+    tl_txt = " / ".join(str(p[0]) for p in pts)
     return {"value": 1.0 / sec_full, "unit": "denoise-steps/s", "cores": cores, "kind": kind,
+            "reference_full_shape": reference_full_shape(shape) if shape else None,
             "fit": {"model": "seconds = a*TL^2 + b*TL per CFG-batched forward, TL = T*(N+1)", "a": qa, "b": qb,
                     "max_relative_residual": round(resid, 4), "quadratic_share_at_workload": round(quad_share, 3),
                     "points": [{"TL": p[0], "seconds": round(p[1], 3), "tflops": round(p[2] / p[1] / 1e12, 3)} for p in pts]},
             "sample": f"{'reference modules + diffusers shim' if kind == 'reference' else 'oracle (port)'} fp32, full "
-                      f"{hp['num_layers']}-layer width-{hp['width']} forwards at B=2, T={Ts}, N in (256, 512, 1024) (TL = 4112 / 8208 / 16400) = "
+                      f"{hp['num_layers']}-layer width-{hp['width']} forwards at B=2, T={Ts}, N in ({ns_txt}) (TL = {tl_txt}) = "
                       f"{sum(p[1] for p in pts):.1f} s of CPU work at {flat / 1e12:.2f} TFLOP/s; a*TL^2+b*TL fit evaluated at "
                       f"TL={TLf}: {sec_full / 60:.1f} min per step - an extrapolation (x{TLf / pts[-1][0]:.0f} in TL beyond "
                       f"the largest sample), not a measurement of the full step"}
@@ -352,9 +377,21 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0, metavar="P", help="single GPU only: print a PROJECTION record instead - rank 0's share of "
                     "a step of a P-rank run timed on this device, beside the modelled xGMI time of the per-layer exchange")
     ap.add_argument("--no-nominal", action="store_true", help="skip the `nominal` sub-record (the shipped architecture, 3 steps) of the headline N=1 line")
+    ap.add_argument("--same-device", action="store_true",
+                    help="DRY RUN of the N > 1 path on a box with ONE GPU: every rank drives cuda:0, the control plane is gloo and the "
+                         "per-layer K/V exchange is the copy-engine back-end (ACTIONMESH_AMD_EXCHANGE=peer; RCCL refuses two ranks on one "
+                         "device).  Executes every line of the world > 1 branch - groups, the sharded HipDenoiser, barriers, the MAX "
+                         "all-reduce of the timing, the JSON - so that a first run on an 8-GPU node cannot fail on a typo; the numbers "
+                         "are NOT a multi-GPU measurement and the line says so (tests/test_multi_gpu.py)")
+    ap.add_argument("--cpu-baseline-deep", action="store_true",
+                    help="cpu_baseline: add the N = 2048 sample (TL = 32 784; minutes of host time) so the fit is evaluated x2 instead of "
+                         "x4 beyond its largest sample.  Off by default: the default run has to finish within a few minutes")
     args = ap.parse_args()
     if args.graph:
         os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
+    if args.same_device:
+        os.environ["ACTIONMESH_AMD_EXCHANGE"] = "peer"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch.distributed as dist
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
@@ -364,14 +401,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.same_device:
+        local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     group = None
+    backend = "gloo" if args.same_device else "nccl"
     if world > 1:
         # lazy communicator creation on the current device (no device_id: eager init would create the CFG-branch
         # sub-groups by communicator split, which not every RCCL build supports)
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
         group = dist.group.WORLD
+    ctl_dev = torch.device("cpu") if backend == "gloo" else dev      # where the control-plane tensors (timing all-reduce) live
+
+    def barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
+
+    def max_over_ranks(seconds):
+        tmax = torch.tensor([seconds], device=ctl_dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
 
     T, N, C, H, NL, S, Dc, Din = SHAPES[args.shape]
     if args.emulate_world:
@@ -401,7 +453,7 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            barrier()
             torch.cuda.synchronize(dev)
 
     loop = sched._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
@@ -415,10 +467,14 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = max_over_ranks(elapsed)
+    model.check_exchange(block=True)
     assert bool(torch.isfinite(init_latent).all()), "non-finite latents"
+    # what the sampler has made of the latents after warmup + steps steps: every rank holds the full tensor (like the reference), so a
+    # 1-rank and an N-rank run of the same command must agree to the sharding tolerance (tests/test_multi_gpu.py compares them)
+    fp_lat = init_latent[0, 1:].double()
+    fingerprint = {"after_steps": total, "rms": float(fp_lat.pow(2).mean().sqrt()), "mean": float(fp_lat.mean()),
+                   "sample": [round(float(x), 6) for x in init_latent[0, -1, ::max(1, N // 8), 0].double().cpu()[:8]]}
     sched2 = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=True)
     loop2 = sched2._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev), framestep=framestep)
     next(loop2)
@@ -429,9 +485,8 @@ def main():
     sync()
     elapsed2 = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed2], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed2 = float(tmax.item())
+        elapsed2 = max_over_ranks(elapsed2)
+    model.check_exchange(block=True)
 
     step_flops = model._engine.step_flops(2, T, N, S)
     steps_per_s = args.steps / elapsed
@@ -464,6 +519,7 @@ def main():
                                          "(identical inputs) - bit-identical latents (tests/test_denoiser_gpu.py::"
                                          "test_exact_shortcuts_are_bit_identical); `value` above executes every operation"},
         "hip_graph": bool(args.graph and world == 1),
+        "latents_fingerprint": fingerprint,
         "end_to_end_video_to_4d_s": None,
         "end_to_end_note": "unmeasured: pretrained weights / assets unreachable offline; the GPU stages chained on synthetic "
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
@@ -476,9 +532,15 @@ def main():
     if rank == 0 and world == 1 and args.shape == "headline" and not args.no_nominal:
         result["nominal"] = nominal_record(dev, args.dtype)             # the shipped architecture next to the headline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S, T, N)
+        result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S, T, N, deep=args.cpu_baseline_deep, shape=args.shape)
+    if args.same_device:
+        result["same_device_dry_run"] = True
+        result["metric"] = "DRY RUN (all ranks on ONE device, gloo control plane, copy-engine exchange) of: " + result["metric"]
+        result["exchange_backend"] = "peer (copy engines, IPC-mapped gather buffers)"
+    elif world > 1:
+        result["exchange_backend"] = os.environ.get("ACTIONMESH_AMD_EXCHANGE", "rccl")
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -78,8 +78,30 @@ def tol_plain(step):
     return min(2e-2 + 2.5e-3 * step, 8e-2)
 
 
+# Stated tolerance of the fp8 (e4m3) self-attention variant at the BASELINE architectures, relative to the reference's OWN
+# reduced-precision curve like the bf16 one:  rel-L2 <= K8 x ref_autocast_curve[step] + EPS8.
+# K8 / EPS8 are MEASURED, not guessed (profiles/r04a_parity_*_fp8.json, MI355X): see DESIGN.md section 2 "fp8 at the BASELINE
+# architectures".  The absolute cap is the bf16 one scaled by the same factor.
+K8, EPS8 = 1.6, 3e-3
+
+
+def tol_curve(dtype, ref, step=None):
+    if dtype == "fp8":
+        return K8 * ref + EPS8
+    return 1.15 * ref + 2e-3
+
+
+def tol_cap(dtype, step):
+    return tol_plain(step) * (K8 / 1.15 if dtype == "fp8" else 1.0)
+
+
+def _tag(name, dtype):
+    return name if dtype == "bf16" else f"{name}_{dtype}"
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 @pytest.mark.parametrize("name", ["full_headline", "full_nominal"])
-def test_full_shape_forward(dev, golden_dir, name):
+def test_full_shape_forward(dev, golden_dir, name, dtype):
     """ONE forward at the FULL benchmarked shapes (VERDICT r02 missing #2) against the reference's own modules: the headline workload
     of bench.py (16 frames x 4096 tokens, width 1024: 65 552-token inflated sequences, 1025 key tiles) and the shipped architecture
     at its shipped size (16 x 2048, width 2048).  The fixture (oracle/make_golden_baseline.py make_full; ~30 min of host time per
@@ -88,33 +110,40 @@ def test_full_shape_forward(dev, golden_dir, name):
     path = os.path.join(golden_dir, f"{name}.npz")
     if not os.path.exists(path):
         pytest.skip(f"{name}.npz not generated (oracle/make_golden_baseline.py {name})")
-    g, cfg, sd, model, inp, _ = _case(name, golden_dir, dev)
+    g, cfg, sd, model, inp, _ = _case(name, golden_dir, dev, attn_dtype=dtype)
     stride = int(g["token_stride"])
     v = _forward(model, inp, float(g["fwd_t"]), dev)
+    n8, n16 = model._engine.attention_counters()
+    assert (n8 > 0 and n16 == 0) if dtype == "fp8" else (n8 == 0 and n16 > 0), (dtype, n8, n16)      # the arithmetic that really ran
     model.cpu()
     ref = torch.from_numpy(g["fwd_velocity_fp32_sub"])
     got = v[:, :, ::stride]
     r = rel(got, ref)
     ref_ac = float(g["fwd_ref_autocast_vs_fp32"]) if "fwd_ref_autocast_vs_fp32" in g.files else None
     rms = float(g["fwd_velocity_rms"])
-    print(f"{name}: full-shape forward rel-L2 vs reference fp32 {r:.3e} on {ref.numel()} sampled values (reference autocast vs its fp32: "
+    print(f"{name} [{dtype}]: full-shape forward rel-L2 vs reference fp32 {r:.3e} on {ref.numel()} sampled values (reference autocast vs its fp32: "
           f"{ref_ac}); velocity rms {float(v.double().pow(2).mean().sqrt()):.4f} (reference {rms:.4f}); max abs {float((got - ref).abs().max()):.3e}")
-    _record(name, dict(forward=r, ref_autocast=ref_ac, max_abs=float((got - ref).abs().max()), rms=rms))
-    assert torch.isfinite(v).all() and r < 2e-2
+    _record(_tag(name, dtype), dict(forward=r, ref_autocast=ref_ac, max_abs=float((got - ref).abs().max()), rms=rms, attn_dtype=dtype))
+    assert torch.isfinite(v).all() and r < tol_cap(dtype, 0)
     if ref_ac is not None:
-        assert r < 1.15 * ref_ac + 2e-3, (r, ref_ac)
+        assert r < tol_curve(dtype, ref_ac), (r, ref_ac)
     assert abs(float(v.double().pow(2).mean().sqrt()) - rms) < 2e-2 * rms
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
 @pytest.mark.parametrize("name", ["arch_headline", "arch_nominal", "arch_headline_50"])
-def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name):
+def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name, dtype):
+    """bf16: the product path.  fp8: `attn_dtype="fp8"` - BASELINE configs[4]'s arithmetic - through the same 21-layer / depth-10-skip
+    architectures and the same 10 / 30 / 50-step sampler loops, against the same reference fixtures; the e4m3 noise of the
+    self-attention is diluted by the bf16 residual stream (DESIGN.md section 2 holds the measured curves)."""
     from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
-    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev)
+    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev, attn_dtype=dtype)
     stride = int(g["token_stride"])
     v = _forward(model, inp, float(g["fwd_t"]), dev)
     r_fwd = rel(v, torch.from_numpy(g["fwd_velocity_fp32"]))
-    print(f"{name}: forward rel-L2 vs reference fp32 {r_fwd:.3e} (reference autocast vs fp32: {float(g['fwd_ref_autocast_vs_fp32']):.3e})")
-    assert torch.isfinite(v).all() and r_fwd < 2e-2
+    print(f"{name} [{dtype}]: forward rel-L2 vs reference fp32 {r_fwd:.3e} (reference autocast vs fp32: {float(g['fwd_ref_autocast_vs_fp32']):.3e})")
+    assert torch.isfinite(v).all() and r_fwd < tol_cap(dtype, 0)
+    assert r_fwd < tol_curve(dtype, float(g["fwd_ref_autocast_vs_fp32"]))
 
     sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
     cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
@@ -130,15 +159,19 @@ def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name):
         last = lat
     assert len(curve) == steps
     final = rel(last.cpu(), torch.from_numpy(g["loop_final_fp32"]))
-    print(f"{name}: per-step latents rel-L2 vs reference fp32: " + " ".join(f"{c:.2e}" for c in curve))
+    print(f"{name} [{dtype}]: per-step latents rel-L2 vs reference fp32: " + " ".join(f"{c:.2e}" for c in curve))
     print(f"{name}: reference autocast(bf16) vs its fp32:       " + " ".join(f"{c:.2e}" for c in ref_curve))
-    print(f"{name}: final full latents rel-L2 {final:.3e}")
-    _record(name, dict(forward=r_fwd, curve=curve, ref_autocast_curve=[float(c) for c in ref_curve], final=final))
+    print(f"{name} [{dtype}]: final full latents rel-L2 {final:.3e}")
+    n8, n16 = model._engine.attention_counters()
+    assert (n8 > 0 and n16 == 0) if dtype == "fp8" else (n8 == 0 and n16 > 0), (dtype, n8, n16)
+    worst = max(c / float(ref_curve[i]) for i, c in enumerate(curve) if i < len(ref_curve) and i >= 2)
+    _record(_tag(name, dtype), dict(forward=r_fwd, curve=curve, ref_autocast_curve=[float(c) for c in ref_curve], final=final,
+                                    attn_dtype=dtype, worst_ratio_to_ref_autocast_from_step_3=worst))
     for i, c in enumerate(curve):
-        assert c < tol_plain(i), (i, c, tol_plain(i))
-        if i < len(ref_curve):       # measured (r02a): the HIP curve tracks the reference's own autocast curve within 2 %
-            assert c < 1.15 * float(ref_curve[i]) + 2e-3, (i, c, float(ref_curve[i]))
-    assert final < tol_plain(steps - 1)
+        assert c < tol_cap(dtype, i), (i, c, tol_cap(dtype, i))
+        if i < len(ref_curve):       # measured (r02a): the bf16 HIP curve tracks the reference's own autocast curve within 2 %
+            assert c < tol_curve(dtype, float(ref_curve[i])), (i, c, float(ref_curve[i]))
+    assert final < tol_cap(dtype, steps - 1)
 
 
 @pytest.mark.parametrize("name", ["arch_headline_peaky", "arch_headline_spiky"])

@@ -84,3 +84,54 @@ def test_copy_engine_exchange_on_real_ranks(world):
         pytest.skip(f"needs {world} GPUs")
     _run(world, tool="peer_selftest")
     _run(world, env_extra={"ACTIONMESH_AMD_EXCHANGE": "peer"})          # the same back-end under HipDenoiser + RCCL control plane
+
+
+def _bench(world, extra=()):
+    """bench.py itself, as the driver launches it (torch.distributed.run for N > 1), with every rank on ONE device."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--shape", "small", "--no-cpu-baseline", *extra]
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), *args, "--same-device"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly ONE JSON line on rank 0, got {len(lines)}:\n" + r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_bench_world_gt_1_branch_runs_on_one_device(dtype):
+    """bench.py's N > 1 branch (process-group init, the CFG x frame sub-groups inside HipDenoiser, the
+    barrier-bracketed timing, the MAX all-reduce over ranks, the one JSON line with n_gpus / parallelism / roofline per rank count) had
+    never executed anywhere.  `--same-device` runs exactly that code with all ranks on cuda:0 (gloo control plane, copy-engine exchange):
+    worlds 2 (pure CFG split) and 4 (CFG x 2 frame shards, one K/V exchange per layer), against the 1-rank run of the same command.
+    Value-independent invariants only - the timing of ranks sharing a device means nothing."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    extra = ("--dtype", dtype)
+    one = _bench(1, extra)
+    assert one["n_gpus"] == 1 and one["config"]["parallelism"] == "single GPU" and "same_device_dry_run" not in one
+    fp1 = one["latents_fingerprint"]
+    launches1 = one["attention_launches"][dtype]
+    for world in (2, 4):
+        d = _bench(world, extra)
+        assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["same_device_dry_run"] is True
+        assert d["metric"].startswith("DRY RUN") and d["scaling"] == "strong" and d["dtype"] == dtype and d["value"] > 0
+        assert d["config"]["parallelism"] == f"cfg-branch x2 * frame-shard x{world // 2}"
+        assert d["exchange_backend"].startswith("peer")
+        # rank 0 runs ONE CFG branch: every layer of every forward is one self-attention launch sequence on it; with frame shards
+        # (world 4) a layer is two phases (local shard, then the remote ones) but still counted per layer by the engine
+        other = "bf16" if dtype == "fp8" else "fp8"
+        assert d["attention_launches"][other] == 0 and d["attention_launches"][dtype] > 0
+        assert d["attention_launches"][dtype] in (launches1, 2 * launches1), (d["attention_launches"], launches1)
+        rf = d["roofline"]
+        assert rf["bound"] == "mfma" and rf["achieved"] > 0 and 0 < rf["frac"] < 1 and rf["launch_ms"] > 0
+        fp = d["latents_fingerprint"]
+        assert fp["after_steps"] == fp1["after_steps"]
+        tol = 5e-2 if dtype == "fp8" else 2e-2          # the sharding tolerance of tools/peer_selftest.py, on O(1) latents
+        assert abs(fp["rms"] - fp1["rms"]) < tol * fp1["rms"], (fp, fp1)
+        assert max(abs(a - b) for a, b in zip(fp["sample"], fp1["sample"])) < tol * max(1.0, fp1["rms"]), (fp, fp1)

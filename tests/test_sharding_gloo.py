@@ -152,7 +152,7 @@ def _worker(rank, world, port, q, cfg_groups=1, overlap=False):
         v_local = sharded_forward(eng, plan, groups[plan.cfg_rank], plan.slice_local(x), t_local)
         if overlap and plan.frame_world > 1:
             assert eng.local_calls == [i for i in range(cfg.num_layers) if eng.is_inflated(i)]
-        v = gather_frames(v_local, plan, None)
+        _buf, v = gather_frames(v_local, plan, None)
         if rank == 0:
             q.put(v)
     finally:

@@ -475,6 +475,507 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(f8_args p) {
   }
 }
 
+// ==================================================================================================================
+// Round 4: the 4 x 64 form of the fp8 attention (VERDICT r03 weak #2 / next #1b).
+//
+// Why: in the 8-wave kernel above the two waves of a SIMD alternate a softmax interval (V, pure VALU: 32 exp2, 32 row-sum adds,
+// 16 packs, the row max) with a matrix interval (M: 8 MFMAs of 64 cycles), a barrier apart.  An interval lasts max(V, M); V alone
+// is ~840 cycles for 512 cycles of MFMA time (a wave issues one instruction per 4 cycles, v_exp_f32 holds the port for two
+// slots), and beside its partner's matrix interval it stretches to ~1110: the matrix pipe is 46 % busy, "the intervals add"
+// (profiles/r03f_*_pmc.csv).  The e4m3 MFMA halved the matrix time per score; the per-score VALU work did not
+// shrink, so the kernel is bound by ONE wave's VALU issue while the partner's VALU sits behind a barrier.
+// Here a workgroup is 4 waves = ONE wave per SIMD, each wave owns 64 query rows (blocks j = 0, 1 of 32) and the whole
+// 512-register file, and every MFMA is threaded through the wave's OWN softmax stream (the structure of am_attention64.hip):
+//     phase 1(t):  O_j += V^T(t-1) P_j(t-1), j = 0, 1        (8 MFMA)  ||  softmax of block 0 of tile t
+//     phase 2(t):  S_j(t+1) = K(t+1) Q_j^T + (5 - m_j)        (8 MFMA)  ||  softmax of block 1 of tile t
+// No interval ever waits for a partner: the VALU stream runs continuously and the MFMAs are issued inside it, 1 per ~18 issue
+// slots; every K8 / V8T fragment read from LDS feeds two MFMAs (one per block): half the ds_reads, LDS-DMA pieces and barriers
+// per MFMA.  O (128 registers) and the Q fragments (32) live in AccVGPRs ("a" asm operands: P.V is an AGPR-form MFMA, QK^T
+// reads its B operand from the accumulator file), the arch file holds scores (block 0: one set, block 1: a ping-pong pair -
+// its softmax runs under its own next QK^T), the packed P (block 0 doubled), the two 5 - m_run splats and FOUR rotating
+// fragment sets shared by V^T and K (set i holds V^T channel block i in phase 1 and K fragment i in phase 2; it is refilled
+// for the next phase one MFMA pair after its last use).
+// Same operands, same numerics and same modes (one pass / save state / resume) as attn_fp8_kernel; the split last block (MODE 3)
+// stays on the 8-wave kernel.  One barrier per tile with a counted vmcnt(8): tile t+1 has landed, tiles t+2, t+3 stay in
+// flight; tile t+4 is staged in iteration t (2 K8 + 2 V8T pieces per wave, in the light row-max gaps).
+// Exact online softmax (running max, deferred re-base at 2^3) - the lazy re-base of the bf16 4x64 kernel needs bf16's exponent
+// range for P; e4m3 holds 2^-9 .. 448.
+// ==================================================================================================================
+#define X_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define X_PIN(x) asm volatile("" : "+v"(x))
+constexpr int X_AHEAD = 4;                 // tiles staged ahead of the one whose K is being multiplied
+
+__device__ __forceinline__ void x_pv(f32x16_t& o, const i32x8_t& v, const i32x8_t& p, int one) {            // o (AGPR) += v x p
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+a"(o) : "v"(v), "v"(p), "v"(one) : "memory");
+}
+__device__ __forceinline__ void x_qk_first(f32x16_t& d, const i32x8_t& k, const i32x8_t& q, const f32x16_t& c, int one) {   // d = k x q + c
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(k), "a"(q), "v"(c), "v"(one) : "memory");
+}
+__device__ __forceinline__ void x_qk_acc(f32x16_t& d, const i32x8_t& k, const i32x8_t& q, int one) {       // d += k x q
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(k), "a"(q), "v"(one) : "memory");
+}
+
+// row max of one 32-query block over the tile's 64 keys: 20 single-instruction steps (four v_max3 chains, the other half-lane)
+struct XRowMax {
+  float a[4];
+  float mx;
+  __device__ __forceinline__ void step(int n, const f32x16_t& sa, const f32x16_t& sb, int hi) {
+    if (n < 4) { a[n] = fmaxf(fmaxf(sa[n], sb[n]), sa[n + 4]); X_PIN(a[n]); }
+    else if (n < 8) { const int i = n - 4; a[i] = fmaxf(fmaxf(a[i], sb[i + 4]), sa[i + 8]); X_PIN(a[i]); }
+    else if (n < 12) { const int i = n - 8; a[i] = fmaxf(fmaxf(a[i], sb[i + 8]), sa[i + 12]); X_PIN(a[i]); }
+    else if (n < 16) { const int i = n - 12; a[i] = fmaxf(a[i], sb[i + 12]); X_PIN(a[i]); }
+    else if (n == 16) { a[2] = fmaxf(a[2], a[3]); X_PIN(a[2]); }
+    else if (n == 17) { mx = fmaxf(fmaxf(a[0], a[1]), a[2]); X_PIN(mx); }
+    else if (n == 18) { a[0] = other_half(mx, hi); X_PIN(a[0]); }
+    else { mx = fmaxf(mx, a[0]); X_PIN(mx); }
+  }
+};
+// exp2 / row sum / e4m3 pack of one block as 80 single-instruction steps (32 v_exp_f32, 32 v_add_f32, 16 v_cvt_pk_fp8_f32), each
+// consumer a round behind the exponentials it reads; element e = 16 kb + r of the block's two score registers sets
+enum XEsKind : int { XES_EX = 0, XES_AD = 1, XES_PK = 2 };
+struct XEsSeq { int n; int cost; int kind[80]; int arg[80]; };
+__device__ __host__ constexpr XEsSeq x_es_seq() {
+  XEsSeq q{};
+  int n = 0;
+  auto put = [&](int k, int a) { q.kind[n] = k; q.arg[n] = a; ++n; };
+  for (int r = 0; r < 16; ++r) {
+    put(XES_EX, 2 * r);
+    put(XES_EX, 2 * r + 1);
+    if (r >= 1) { put(XES_AD, 2 * r - 2); put(XES_AD, 2 * r - 1); put(XES_PK, r - 1); }
+  }
+  put(XES_AD, 30); put(XES_AD, 31); put(XES_PK, 15);
+  q.n = n;
+  for (int i = 0; i < n; ++i) q.cost += q.kind[i] == XES_EX ? 2 : 1;      // issue slots: v_exp_f32 holds the port for two
+  return q;
+}
+constexpr int X_ES_GAPS = 6;               // the 80 steps go behind MFMAs 2 .. 7 of a phase
+struct XEsTab { int lo[X_ES_GAPS + 1]; };
+__device__ __host__ constexpr XEsTab x_es_tab(const XEsSeq& q) {
+  XEsTab t{};
+  for (int i = 0; i <= X_ES_GAPS; ++i) {
+    int n = 0, c = 0;
+    while (n < q.n && c * X_ES_GAPS < i * q.cost) { c += q.kind[n] == XES_EX ? 2 : 1; ++n; }
+    t.lo[i] = n;
+  }
+  t.lo[X_ES_GAPS] = q.n;
+  return t;
+}
+template <int ABL>
+struct XExpSumPack {
+  static constexpr XEsSeq SEQ = x_es_seq();
+  float rs[4];
+  __device__ __forceinline__ void init() { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; }
+  __device__ __forceinline__ static float get(const f32x16_t& sa, const f32x16_t& sb, int e) { return e < 16 ? sa[e] : sb[e - 16]; }
+  __device__ __forceinline__ void step(int n, f32x16_t& sa, f32x16_t& sb, i32x8_t& w) {
+    const int k = SEQ.kind[n], a = SEQ.arg[n];
+    if (k == XES_EX) {
+      float v = (ABL & 1) ? get(sa, sb, a) : __builtin_amdgcn_exp2f(get(sa, sb, a));
+      X_PIN(v);
+      if (a < 16) sa[a] = v; else sb[a - 16] = v;
+    } else if (k == XES_AD) {
+      rs[a & 3] += get(sa, sb, a);
+      X_PIN(rs[a & 3]);
+    } else {                              // pair a = elements 2a, 2a+1 -> half (a & 1) of word a >> 1 (byte j = 16 kb + r of the B operand)
+      int x = w[a >> 1];
+      x = (a & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(get(sa, sb, 2 * a), get(sa, sb, 2 * a + 1), x, true)
+                  : __builtin_amdgcn_cvt_pk_fp8_f32(get(sa, sb, 2 * a), get(sa, sb, 2 * a + 1), x, false);
+      X_PIN(x);
+      w[a >> 1] = x;
+    }
+  }
+  __device__ __forceinline__ float total() const { return (rs[0] + rs[1]) + (rs[2] + rs[3]); }
+};
+
+// ABL: 1 no exponentials, 2 no LDS-DMA in the loop, 8 no softmax steps at all (timing ablations, numerically meaningless).
+// MODE: 0 one pass, 1 save the un-normalised (O, m, l), 2 resume from it (attn_fp8_kernel above).  PROF: s_memtime stamps.
+template <int ABL, int MODE, bool PROF = false>
+__global__ __launch_bounds__(256, 1) void attn_fp8x64_kernel(f8_args p, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int qblk = p.qblk_base + blockIdx.x, sh = blockIdx.y;          // sh = seq * heads + head
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+  const int q0 = qblk * 256 + wave * 64;                               // block j: rows q0 + 32 j + l31
+  auto stamp = [&](int t, int slot) __attribute__((always_inline)) {
+    if (PROF && blockIdx.x == 0 && sh == 0 && t >= 64 && t < 72) {
+      unsigned long long c;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c));
+      if (lane == 0) prof[(wave * 8 + (t - 64)) * 8 + slot] = c;
+    }
+  };
+
+  // ---- Q fragments of both blocks (B operand of QK^T), parked in AccVGPRs: lane (row l31, half hi), k-step s: channels 64 s + 32 hi ..
+  i32x8_t qf[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint8_t* qp = p.Q + ((int64_t)sh * p.sq_pad + q0 + 32 * j + l31) * HD8 + hi * 32;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qp + s * 64);
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qp + s * 64 + 16);
+      qf[j][s] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+a"(qf[j][s]));       // landed (and in the accumulator file) before any LDS-DMA is counted
+
+  // ---- accumulators and softmax state
+  f32x16_t o[2][4];
+  float m_run[2] = {P_SHIFT, P_SHIFT}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][cb][r] = 0.f;
+  if (MODE == 2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float* sp = p.state + ((int64_t)sh * p.sq_pad + q0 + 32 * j + l31) * F8_STATE_LD;
+      m_run[j] = sp[HD8];
+      l_run[j] = hi == 0 ? sp[HD8 + 1] : 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[j][cb][4 * g + i] = t4[i];
+        }
+        asm volatile("" : "+a"(o[j][cb]));
+      }
+      asm volatile("" : "+v"(m_run[j]), "+v"(l_run[j]));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+a"(o[j][cb]));
+  int one = SCALE_ONE;
+  asm volatile("" : "+v"(one));
+  f32x16_t bs[2];                                           // P_SHIFT - m_run splats: SrcC of the first QK^T MFMAs, rewritten on a re-base only
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bs[j][r] = P_SHIFT - m_run[j];
+    X_PIN(bs[j]);
+  }
+
+  // ---- LDS-DMA: a tile = 8 pieces of K8 (8 key rows each) + 8 of V8T (16 channel rows each), 1 KiB per wave-instruction; wave w
+  // moves pieces w and w + 4 of each.  Lane-linear destination, swizzle on the source unit (K: unit ^ ((row >> 1) & 7), V^T:
+  // unit ^ ((row >> 2) & 3)) - both are the same for pieces w and w + 4, so one lane offset serves both.
+  const int all_tiles = p.nchunks * p.tiles_per_chunk;
+  const int kr = wave * 8 + (lane >> 3);
+  const uint32_t k_lane_off = (uint32_t)kr * HD8 + (uint32_t)(((lane & 7) ^ ((kr >> 1) & 7)) << 4);
+  const int vr = wave * 16 + (lane >> 2);
+  const uint32_t v_lane_off = (uint32_t)vr * (uint32_t)p.sk_pad + (uint32_t)(((lane & 3) ^ ((vr >> 2) & 3)) << 4);
+  const uint8_t* base_k = p.K + (int64_t)sh * p.sk_pad * HD8;
+  const uint8_t* base_v = p.Vt + (int64_t)sh * p.sk_pad * HD8;
+  int st_n = 0, st_ti = 0, st_pos = 0;
+  auto chunk_off = [&](int pos) __attribute__((always_inline)) {
+    int c = p.chunk_first + pos;
+    if (p.chunk_total > 0 && c >= p.chunk_total) c -= p.chunk_total;
+    return (int64_t)c * p.chunk_stride;
+  };
+  const uint8_t* st_k = base_k + chunk_off(0);
+  const uint8_t* st_v = base_v + chunk_off(0);
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)smem);
+  auto uniform = [](const uint8_t* q) __attribute__((always_inline)) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hh = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const uint8_t*>(((uint64_t)hh << 32) | lo);
+  };
+  // one piece: scalar base + 32-bit lane offset -> LDS at (M0) + lane * 16; asm: hipcc neither tracks it nor pads it (the counted
+  // vmcnt in front of the tile barrier is the only wait there is)
+  auto dma_piece = [&](const uint8_t* src, uint32_t lane_off, unsigned lds_off) __attribute__((always_inline)) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(smem_lds + lds_off);
+    const uint8_t* s = uniform(src);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(s), "s"(lds) : "memory");
+  };
+  auto stage_k = [&](int i) __attribute__((always_inline)) {       // piece wave + 4 i of the K8 tile under the cursor
+    dma_piece(st_k + i * (32 * HD8), k_lane_off, (unsigned)((st_n & (NSTAGE - 1)) * STAGE_BYTES + (wave + 4 * i) * 1024));
+  };
+  auto stage_v = [&](int i) __attribute__((always_inline)) {
+    dma_piece(st_v + (int64_t)i * 64 * p.sk_pad, v_lane_off, (unsigned)((st_n & (NSTAGE - 1)) * STAGE_BYTES + 8192 + (wave + 4 * i) * 1024));
+  };
+  auto stage_advance = [&]() __attribute__((always_inline)) {      // past the end of the stream the cursor stays on the last tile
+    ++st_n;
+    if (st_n < all_tiles) {
+      if (st_ti == p.tiles_per_chunk - 1) {
+        st_ti = 0;
+        ++st_pos;
+        st_k = base_k + chunk_off(st_pos);
+        st_v = base_v + chunk_off(st_pos);
+      } else {
+        ++st_ti;
+        st_k += KT * HD8;
+        st_v += KT;
+      }
+    }
+  };
+
+  // ---- fragment addresses (as in attn_fp8_kernel): K8 fragment n = (kb = n & 1, s = n >> 1): key 32 kb + l31, units 4 s + 2 hi + {0, 1};
+  // V8T fragment cb: channel 32 cb + l31, units 2 hi + {0, 1}
+  const int ksw = (l31 >> 1) & 7, vsw = (l31 >> 2) & 3;
+  int k_off[2][2], v_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) k_off[s][e] = l31 * HD8 + (((4 * s + 2 * hi + e) ^ ksw) << 4);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) v_off[e] = 8192 + l31 * 64 + (((2 * hi + e) ^ vsw) << 4);
+  auto k_frag = [&](int tt, int n) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + (n & 1) * 32 * HD8;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][1]);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  auto v_frag = [&](int tt, int cb) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + cb * 32 * 64;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + v_off[0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + v_off[1]);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+
+  // ---- pipeline registers (arch file)
+  f32x16_t s0[2];              // block 0: S(t) on entry of an iteration, S(t+1) on exit
+  f32x16_t s1[2][2];           // block 1: ping-pong, S(t) in s1[cur], S(t+1) born in s1[cur ^ 1]
+  i32x8_t p0[2], p1;           // packed P: block 0 doubled (P(t) is born while P(t-1) is multiplied), block 1 single
+  i32x8_t fr[4];               // rotating fragment sets
+  const i32x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  p0[0] = p0[1] = p1 = zero8;
+  X_PIN(p0[0]); X_PIN(p0[1]); X_PIN(p1);
+  const int tail_valid = p.sk - (p.tiles_per_chunk - 1) * KT;
+  int tic = 0;
+
+  // ---- prologue: tiles 0 .. 3 in flight; V8T of ring slot 7 zeroed (iteration 0 reads "V8T(-1)" fragment 3 from it: P(-1) = 0, but
+  // 0 x NaN byte patterns would poison O); S(0) of both blocks
+#pragma unroll
+  for (int a = 0; a < X_AHEAD; ++a) {
+    stage_k(0); stage_k(1); stage_v(0); stage_v(1);
+    stage_advance();
+  }
+  {
+    unsigned char* z = smem + 7 * STAGE_BYTES + 8192 + tid * 32;
+    *reinterpret_cast<u32x4_t*>(z) = u32x4_t{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4_t*>(z + 16) = u32x4_t{0u, 0u, 0u, 0u};
+  }
+  asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // tile 0 (tiles 1 .. 3 = 12 pieces stay in flight)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) fr[n] = k_frag(0, n);
+  x_qk_first(s0[0], fr[0], qf[0][0], bs[0], one);
+  x_qk_first(s0[1], fr[1], qf[0][0], bs[0], one);
+  x_qk_first(s1[0][0], fr[0], qf[1][0], bs[1], one);
+  x_qk_first(s1[0][1], fr[1], qf[1][0], bs[1], one);
+  x_qk_acc(s0[0], fr[2], qf[0][1], one);
+  x_qk_acc(s0[1], fr[3], qf[0][1], one);
+  x_qk_acc(s1[0][0], fr[2], qf[1][1], one);
+  x_qk_acc(s1[0][1], fr[3], qf[1][1], one);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]));   // operands fetched
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { fr[n] = zero8; X_PIN(fr[n]); }       // "V8T(-1)" = 0
+
+  // rare: keys past the end of a chunk (its last tile), once per chunk
+  auto mask_tail = [&](f32x16_t& sa, f32x16_t& sb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if ((r & 3) + 8 * (r >> 2) + 4 * hi >= tail_valid) sa[r] = -INFINITY;
+      if (32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= tail_valid) sb[r] = -INFINITY;
+    }
+  };
+  auto o_settle = [&](int j) __attribute__((always_inline)) {          // in-flight P.V results of block j have landed (asm MFMAs: nothing is padded)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(o[j][0]), "+a"(o[j][1]), "+a"(o[j][2]), "+a"(o[j][3]));
+  };
+  auto o_scale = [&](int j, float alpha) __attribute__((always_inline)) {
+    o_settle(j);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][cb][r] *= alpha;
+      asm volatile("" : "+a"(o[j][cb]));
+      X_FENCE();                          // the rare path runs with every register of the loop live: 16 temporaries at a time
+    }
+  };
+
+  // ---- one tile
+  auto iteration = [&](const int t, f32x16_t (&s1c)[2], f32x16_t (&s1n)[2], i32x8_t& p0c, i32x8_t& p0n) __attribute__((always_inline)) {
+    stamp(t, 0);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");      // tile t+1 has landed everywhere (tiles t+2, t+3 in flight)
+    stamp(t, 1);
+    const bool first = MODE != 2 && t == 0;
+    const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
+    tic = last_of_chunk ? 0 : tic + 1;
+    const bool masked = last_of_chunk && tail_valid < KT;
+    XRowMax rm;
+    XExpSumPack<ABL> es;
+    constexpr XEsTab ES = x_es_tab(es.SEQ);
+    auto es_gap = [&](int gap, f32x16_t& sa, f32x16_t& sb, i32x8_t& w) __attribute__((always_inline)) {
+      if (!(ABL & 8))
+#pragma unroll
+        for (int n = ES.lo[gap]; n < ES.lo[gap + 1]; ++n) es.step(n, sa, sb, w);
+    };
+    auto rm_gap = [&](int half, const f32x16_t& sa, const f32x16_t& sb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 10 * half; n < 10 * half + 10; ++n) rm.step(n, sa, sb, hi);
+    };
+
+    // ===== phase 1: O_j += V^T(t-1) P_j(t-1) || softmax of block 0; K8(t+4) staged; K8(t+1) fragments fetched =====
+    if (masked) { asm volatile("" ::: "memory"); mask_tail(s0[0], s0[1]); }
+    X_FENCE();
+    x_pv(o[0][0], fr[0], p0c, one);
+    if (!(ABL & 2)) stage_k(0);
+    rm_gap(0, s0[0], s0[1]);
+    X_FENCE();
+    x_pv(o[1][0], fr[0], p1, one);
+    if (!(ABL & 2)) stage_k(1);
+    fr[3] = v_frag(t + 7, 3);                       // V8T(t-1), the set K8(t) fragment 3 left one pair ago   ((t - 1) & 7 == (t + 7) & 7)
+    rm_gap(1, s0[0], s0[1]);
+    X_FENCE();
+    stamp(t, 2);
+    bool flag0 = false;
+    float alpha0 = 1.f;
+    if (first || __builtin_amdgcn_ballot_w64(rm.mx > P_SHIFT + DEFER_T) != 0) {     // rare: re-base block 0
+      const float delta = first ? rm.mx - P_SHIFT : fmaxf(rm.mx - P_SHIFT, 0.f);
+      alpha0 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      l_run[0] *= alpha0;
+      m_run[0] += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[0][r] -= delta; s0[1][r] -= delta; bs[0][r] = P_SHIFT - m_run[0]; }
+      flag0 = true;                                  // O_0 is scaled at the end of the phase: its P.V of tile t-1 is being issued now
+    }
+    es.init();
+    X_FENCE();
+    x_pv(o[0][1], fr[1], p0c, one);
+    es_gap(0, s0[0], s0[1], p0n);
+    X_FENCE();
+    x_pv(o[1][1], fr[1], p1, one);
+    fr[0] = k_frag(t + 1, 0);
+    es_gap(1, s0[0], s0[1], p0n);
+    X_FENCE();
+    x_pv(o[0][2], fr[2], p0c, one);
+    es_gap(2, s0[0], s0[1], p0n);
+    X_FENCE();
+    x_pv(o[1][2], fr[2], p1, one);
+    fr[1] = k_frag(t + 1, 1);
+    es_gap(3, s0[0], s0[1], p0n);
+    X_FENCE();
+    x_pv(o[0][3], fr[3], p0c, one);
+    es_gap(4, s0[0], s0[1], p0n);
+    X_FENCE();
+    x_pv(o[1][3], fr[3], p1, one);
+    fr[2] = k_frag(t + 1, 2);
+    es_gap(5, s0[0], s0[1], p0n);
+    X_FENCE();
+    stamp(t, 3);
+    l_run[0] += es.total();
+    if (flag0) o_scale(0, alpha0);
+
+    // ===== phase 2: S_j(t+1) = K8(t+1) Q_j^T || softmax of block 1; V8T(t+4) staged; V8T(t) fragments fetched =====
+    if (masked) { asm volatile("" ::: "memory"); mask_tail(s1c[0], s1c[1]); }
+    X_FENCE();
+    x_qk_first(s0[0], fr[0], qf[0][0], bs[0], one);
+    if (!(ABL & 2)) stage_v(0);
+    rm_gap(0, s1c[0], s1c[1]);
+    X_FENCE();
+    x_qk_first(s0[1], fr[1], qf[0][0], bs[0], one);
+    if (!(ABL & 2)) stage_v(1);
+    fr[3] = k_frag(t + 1, 3);
+    rm_gap(1, s1c[0], s1c[1]);
+    X_FENCE();
+    stamp(t, 4);
+    if (first || __builtin_amdgcn_ballot_w64(rm.mx > P_SHIFT + DEFER_T) != 0) {     // rare: re-base block 1 (its QK^T MFMAs come behind)
+      const float delta = first ? rm.mx - P_SHIFT : fmaxf(rm.mx - P_SHIFT, 0.f);
+      const float a1 = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      l_run[1] *= a1;
+      m_run[1] += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s1c[0][r] -= delta; s1c[1][r] -= delta; bs[1][r] = P_SHIFT - m_run[1]; }
+      o_scale(1, a1);                                // O_1 is complete through tile t-1
+    }
+    es.init();
+    X_FENCE();
+    x_qk_first(s1n[0], fr[0], qf[1][0], bs[1], one);
+    es_gap(0, s1c[0], s1c[1], p1);
+    X_FENCE();
+    x_qk_first(s1n[1], fr[1], qf[1][0], bs[1], one);
+    es_gap(1, s1c[0], s1c[1], p1);
+    X_FENCE();
+    x_qk_acc(s0[0], fr[2], qf[0][1], one);
+    fr[0] = v_frag(t, 0);
+    es_gap(2, s1c[0], s1c[1], p1);
+    X_FENCE();
+    x_qk_acc(s1n[0], fr[2], qf[1][1], one);
+    fr[1] = v_frag(t, 1);
+    es_gap(3, s1c[0], s1c[1], p1);
+    X_FENCE();
+    x_qk_acc(s0[1], fr[3], qf[0][1], one);
+    es_gap(4, s1c[0], s1c[1], p1);
+    X_FENCE();
+    x_qk_acc(s1n[1], fr[3], qf[1][1], one);
+    fr[2] = v_frag(t, 2);
+    es_gap(5, s1c[0], s1c[1], p1);
+    X_FENCE();
+    stamp(t, 5);
+    l_run[1] += es.total();
+    if (!(ABL & 2)) stage_advance();
+  };
+
+  int t = 0;
+  for (; t + 1 < all_tiles; t += 2) {
+    iteration(t, s1[0], s1[1], p0[0], p0[1]);
+    iteration(t + 1, s1[1], s1[0], p0[1], p0[0]);
+  }
+  if (t < all_tiles) iteration(t, s1[0], s1[1], p0[0], p0[1]);
+  const bool odd = (all_tiles & 1) != 0;
+  // ---- drain: the scores of the tile past the end are still in flight (their registers are held until they land); O += V^T(n-1) P(n-1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA piece may outlive the workgroup's LDS allocation
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0][0]), "+v"(s1[0][1]), "+v"(s1[1][0]), "+v"(s1[1][1]));
+  fr[3] = v_frag(all_tiles - 1, 3);
+  {
+    const i32x8_t& p0last = odd ? p0[1] : p0[0];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      x_pv(o[0][cb], fr[cb], p0last, one);
+      x_pv(o[1][cb], fr[cb], p1, one);
+    }
+  }
+  o_settle(0);
+  o_settle(1);
+
+  // ---- normalise and store: lane (row l31, half hi) holds channels 32 cb + 8 g + 4 hi .. + 3 in registers 4 g .. 4 g + 3
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qrow = q0 + 32 * j + l31;
+    float l = l_run[j];
+    l += other_half(l, hi);
+    if (MODE == 1) {
+      float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi) = f32x4_t{o[j][cb][4 * g], o[j][cb][4 * g + 1], o[j][cb][4 * g + 2], o[j][cb][4 * g + 3]};
+      if (hi == 0) { sp[HD8] = m_run[j]; sp[HD8 + 1] = l; }
+      continue;
+    }
+    if (qrow < p.sq) {
+      const float inv = 1.f / l;
+      bf16_t* op = p.O + ((int64_t)seq * p.sq + qrow) * p.ldo + head * HD8;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2_t w = {pack_bf2(o[j][cb][4 * g] * inv, o[j][cb][4 * g + 1] * inv), pack_bf2(o[j][cb][4 * g + 2] * inv, o[j][cb][4 * g + 3] * inv)};
+          *reinterpret_cast<u32x2_t*>(op + cb * 32 + 8 * g + 4 * hi) = w;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 int am_attention_combine_launch(const am_attn_args* a, const float* part, int Z, int qblk_base, int rows, void* stream);   // am_attention.hip

@@ -247,8 +247,10 @@ def test_attention_fp8_peaky_scores_and_rebase(dev):
 
 
 def test_model_forward_with_fp8_attention(dev, golden_dir):
-    """am_config.attn_fp8: the denoiser with its inflated self-attention on the fp8 kernel stays within 5e-2 of the fp32
-    reference velocity (bf16 path: 1e-2) on the reference-generated fixture."""
+    """am_config.attn_fp8: the denoiser with its inflated self-attention on the fp8 kernel on the reference-generated toy fixture: measured
+    1.03e-2 from the fp32 reference velocity (bf16 path 0.85e-2), stated 1.5e-2 (round 3 stated 5e-2).  The BASELINE
+    architectures - 21 layers, depth-10 skips, 10 / 30 / 50 sampler steps, the full 65 552-token shape - are pinned in
+    tests/test_baseline_arch_gpu.py (attn_dtype = fp8 cases) RELATIVE to the reference's own reduced-precision curve."""
     import os
     import numpy as np
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser
@@ -269,4 +271,4 @@ def test_model_forward_with_fp8_attention(dev, golden_dir):
     ref = torch.from_numpy(g["fwd_velocity_fp32"])
     r = float((v.float().cpu() - ref).norm() / ref.norm())
     print(f"denoiser forward with fp8 self-attention: rel-L2 vs reference fp32 {r:.3e}")
-    assert r < 5e-2
+    assert r < 1.5e-2

@@ -80,9 +80,13 @@ def tol_plain(step):
 
 # Stated tolerance of the fp8 (e4m3) self-attention variant at the BASELINE architectures, relative to the reference's OWN
 # reduced-precision curve like the bf16 one:  rel-L2 <= K8 x ref_autocast_curve[step] + EPS8.
-# K8 / EPS8 are MEASURED, not guessed (profiles/r04a_parity_*_fp8.json, MI355X): see DESIGN.md section 2 "fp8 at the BASELINE
-# architectures".  The absolute cap is the bf16 one scaled by the same factor.
-K8, EPS8 = 1.6, 3e-3
+# MEASURED on MI355X (profiles/r04a_parity_*_fp8.json): the fp8 curve sits 3-7 % above the reference's own autocast(bf16) curve at
+# every step of every case - arch_headline 30 steps 1.44e-2 vs 1.40e-2, arch_headline_50 1.34e-2 vs 1.30e-2 after step 50,
+# arch_nominal 1.82e-2 vs 1.76e-2, one forward at the FULL headline / nominal shapes 1.020e-2 / 1.026e-2 vs 0.987e-2 / 0.993e-2 -
+# i.e. the e4m3 noise of the self-attention is diluted by the bf16 residual stream to a few per cent of the bf16 rounding error
+# the reference itself carries, through 21 layers, depth-10 skips and 50 sampler steps alike (worst ratio 1.065, early steps of
+# arch_nominal).  So the fp8 path is held to the SAME statement as the bf16 path: 1.15 x the reference's curve + 2e-3.
+K8, EPS8 = 1.15, 2e-3
 
 
 def tol_curve(dtype, ref, step=None):

@@ -781,10 +781,12 @@ __global__ __launch_bounds__(256, 1) void attn_fp8x64_kernel(f8_args p, unsigned
 
   // rare: keys past the end of a chunk (its last tile), once per chunk
   auto mask_tail = [&](f32x16_t& sa, f32x16_t& sb) __attribute__((always_inline)) {
+    int tv = tail_valid - 4 * hi;
+    asm volatile("" : "+v"(tv));          // the 32 lane masks are computed here, in the rare branch, not held in 64 SGPRs across the loop
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if ((r & 3) + 8 * (r >> 2) + 4 * hi >= tail_valid) sa[r] = -INFINITY;
-      if (32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= tail_valid) sb[r] = -INFINITY;
+      if ((r & 3) + 8 * (r >> 2) >= tv) sa[r] = -INFINITY;
+      if (32 + (r & 3) + 8 * (r >> 2) >= tv) sb[r] = -INFINITY;
     }
   };
   auto o_settle = [&](int j) __attribute__((always_inline)) {          // in-flight P.V results of block j have landed (asm MFMAs: nothing is padded)
@@ -976,6 +978,315 @@ __global__ __launch_bounds__(256, 1) void attn_fp8x64_kernel(f8_args p, unsigned
   }
 }
 
+// ==================================================================================================================
+// The product form (round 4): 8 waves x 32 rows again - TWO waves per SIMD - but FREE-RUNNING: each wave threads its 8 MFMAs through
+// its own softmax stream as the 4 x 64 form above does (4 P.V MFMAs of tile t-1 and 4 QK^T MFMAs of tile t+1 inside the softmax of
+// tile t), and there is ONE barrier per tile (LDS-DMA visibility) instead of the two that forced the ping-pong.  What round 4's
+// measurements said (profiles/r04b_*): the fp8 attention is bound by the VALU PIPE, not by issue slots - v_exp_f32 is a quarter-rate
+// instruction (16 cycles per wave64; 64 of them per 64 x 64 score tile = 1024 cycles = the tile's whole MFMA time) and the row sums,
+// packs and row max add ~550 more: ~1570 VALU cycles per SIMD and tile against 1024 MFMA cycles.  The ping-pong kernel leaves that
+// pipe idle whenever its softmax wave stalls (its partner is in its matrix interval: 8 MFMAs, 16 ds_reads, no VALU to offer) - 2226
+// cycles per tile; the 4 x 64 form has nobody to cover ANY stall of its single wave (~150 cycles per LDS-DMA piece, the barrier, the
+// scalar tail: 3400 cycles per tile, 12 % slower).  Two free-running waves per SIMD cover each other's stalls with VALU work.
+// Registers: 256 per wave; O (64) and Q (16) in AccVGPRs, scores ping-pong (S(t+1) is born while S(t) is exponentiated), P doubled,
+// four rotating fragment sets (V^T channel block i at MFMA i, K fragment i at MFMA 4 + i).
+// ==================================================================================================================
+// all-arch-VGPR forms of the MFMA wrappers for the two-waves-per-SIMD kernel below: as soon as a kernel names an AccVGPR hipcc splits a
+// 256-register budget 128 / 128 and spills the arch side into the accumulator side; without one it hands out all 256 as arch VGPRs
+__device__ __forceinline__ void p_pv(f32x16_t& o, const i32x8_t& v, const i32x8_t& p, int one) {
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(o) : "v"(v), "v"(p), "v"(one) : "memory");
+}
+__device__ __forceinline__ void p_qk_first(f32x16_t& d, const i32x8_t& k, const i32x8_t& q, const f32x16_t& c, int one) {
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(k), "v"(q), "v"(c), "v"(one) : "memory");
+}
+__device__ __forceinline__ void p_qk_acc(f32x16_t& d, const i32x8_t& k, const i32x8_t& q, int one) {
+  asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(k), "v"(q), "v"(one) : "memory");
+}
+template <int ABL, int MODE, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned long long* prof) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int qblk = p.qblk_base + blockIdx.x, sh = blockIdx.y;
+  const int seq = sh / p.heads, head = sh - seq * p.heads;
+  const int qrow = qblk * 256 + wave * 32 + l31;
+  auto stamp = [&](int t, int slot) __attribute__((always_inline)) {
+    if (PROF && blockIdx.x == 0 && sh == 0 && t >= 64 && t < 72) {
+      unsigned long long c;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c));
+      if (lane == 0) prof[(wave * 8 + (t - 64)) * 8 + slot] = c;
+    }
+  };
+
+  i32x8_t qf[2];
+  {
+    const uint8_t* qp = p.Q + ((int64_t)sh * p.sq_pad + qrow) * HD8 + hi * 32;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const u32x4_t a = *reinterpret_cast<const u32x4_t*>(qp + s * 64);
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(qp + s * 64 + 16);
+      qf[s] = i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(qf[s]));
+  }
+  f32x16_t o[4];
+  float m_run = P_SHIFT, l_run = 0.f;
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+  if (MODE == 2) {
+    const float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
+    m_run = sp[HD8];
+    l_run = hi == 0 ? sp[HD8 + 1] : 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[cb][4 * g + i] = t4[i];
+      }
+    asm volatile("" : "+v"(m_run), "+v"(l_run));
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(o[cb]));
+  int one = SCALE_ONE;
+  asm volatile("" : "+v"(one));
+  f32x16_t bs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bs[r] = P_SHIFT - m_run;
+  X_PIN(bs);
+
+  // ---- LDS-DMA: per tile every wave moves one 1 KiB piece of K8 (8 key rows) and one of V8T (16 channel rows)
+  const int all_tiles = p.nchunks * p.tiles_per_chunk;
+  const int kr = wave * 8 + (lane >> 3);
+  const uint32_t k_lane_off = (uint32_t)kr * HD8 + (uint32_t)(((lane & 7) ^ ((kr >> 1) & 7)) << 4);
+  const int vr = wave * 16 + (lane >> 2);
+  const uint32_t v_lane_off = (uint32_t)vr * (uint32_t)p.sk_pad + (uint32_t)(((lane & 3) ^ ((vr >> 2) & 3)) << 4);
+  const uint8_t* base_k = p.K + (int64_t)sh * p.sk_pad * HD8;
+  const uint8_t* base_v = p.Vt + (int64_t)sh * p.sk_pad * HD8;
+  int st_n = 0, st_ti = 0, st_pos = 0;
+  auto chunk_off = [&](int pos) __attribute__((always_inline)) {
+    int c = p.chunk_first + pos;
+    if (p.chunk_total > 0 && c >= p.chunk_total) c -= p.chunk_total;
+    return (int64_t)c * p.chunk_stride;
+  };
+  const uint8_t* st_k = base_k + chunk_off(0);
+  const uint8_t* st_v = base_v + chunk_off(0);
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)smem);
+  auto uniform = [](const uint8_t* q) __attribute__((always_inline)) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hh = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const uint8_t*>(((uint64_t)hh << 32) | lo);
+  };
+  auto dma_piece = [&](const uint8_t* src, uint32_t lane_off, unsigned lds_off) __attribute__((always_inline)) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(smem_lds + lds_off);
+    const uint8_t* s = uniform(src);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(s), "s"(lds) : "memory");
+  };
+  auto stage_k = [&]() __attribute__((always_inline)) { dma_piece(st_k, k_lane_off, (unsigned)((st_n & (NSTAGE - 1)) * STAGE_BYTES + wave * 1024)); };
+  auto stage_v = [&]() __attribute__((always_inline)) { dma_piece(st_v, v_lane_off, (unsigned)((st_n & (NSTAGE - 1)) * STAGE_BYTES + 8192 + wave * 1024)); };
+  auto stage_advance = [&]() __attribute__((always_inline)) {
+    ++st_n;
+    if (st_n < all_tiles) {
+      if (st_ti == p.tiles_per_chunk - 1) {
+        st_ti = 0;
+        ++st_pos;
+        st_k = base_k + chunk_off(st_pos);
+        st_v = base_v + chunk_off(st_pos);
+      } else {
+        ++st_ti;
+        st_k += KT * HD8;
+        st_v += KT;
+      }
+    }
+  };
+
+  const int ksw = (l31 >> 1) & 7, vsw = (l31 >> 2) & 3;
+  int k_off[2][2], v_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) k_off[s][e] = l31 * HD8 + (((4 * s + 2 * hi + e) ^ ksw) << 4);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) v_off[e] = 8192 + l31 * 64 + (((2 * hi + e) ^ vsw) << 4);
+  auto k_frag = [&](int tt, int n) __attribute__((always_inline)) {          // fragment n = (kb = n & 1, s = n >> 1)
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + (n & 1) * 32 * HD8;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][1]);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+  auto v_frag = [&](int tt, int cb) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + cb * 32 * 64;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + v_off[0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + v_off[1]);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+
+  f32x16_t sc[2][2];           // ping-pong: S(t) in sc[cur], S(t+1) born in sc[cur ^ 1]
+  i32x8_t pf[2];               // P(t-1) in pf[cur] (being multiplied), P(t) born in pf[cur ^ 1]
+  i32x8_t fr[4];
+  const i32x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  pf[0] = pf[1] = zero8;
+  X_PIN(pf[0]); X_PIN(pf[1]);
+  const int tail_valid = p.sk - (p.tiles_per_chunk - 1) * KT;
+  int tic = 0;
+
+  // ---- prologue: tiles 0 .. 3 in flight; V8T of ring slot 7 zeroed ("V8T(-1)": P(-1) = 0, but stale LDS bytes may be NaN patterns)
+#pragma unroll
+  for (int a = 0; a < X_AHEAD; ++a) { stage_k(); stage_v(); stage_advance(); }
+  *reinterpret_cast<u32x4_t*>(smem + 7 * STAGE_BYTES + 8192 + tid * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // tile 0 (tiles 1 .. 3 = 6 pieces stay in flight)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) fr[n] = k_frag(0, n);
+  p_qk_first(sc[0][0], fr[0], qf[0], bs, one);
+  p_qk_first(sc[0][1], fr[1], qf[0], bs, one);
+  p_qk_acc(sc[0][0], fr[2], qf[1], one);
+  p_qk_acc(sc[0][1], fr[3], qf[1], one);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]));
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { fr[n] = zero8; X_PIN(fr[n]); }
+
+  auto o_settle = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+  };
+
+  auto iteration = [&](const int t, f32x16_t (&scc)[2], f32x16_t (&scn)[2], i32x8_t& pc, i32x8_t& pn) __attribute__((always_inline)) {
+    stamp(t, 0);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");      // tile t+1 has landed everywhere (tiles t+2, t+3 in flight)
+    stamp(t, 1);
+    const bool first = MODE != 2 && t == 0;
+    const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
+    tic = last_of_chunk ? 0 : tic + 1;
+    XRowMax rm;
+    XExpSumPack<ABL> es;
+    constexpr XEsTab ES = x_es_tab(es.SEQ);
+    auto es_gap = [&](int gap) __attribute__((always_inline)) {
+      if (!(ABL & 8))
+#pragma unroll
+        for (int n = ES.lo[gap]; n < ES.lo[gap + 1]; ++n) es.step(n, scc[0], scc[1], pn);
+    };
+    if (last_of_chunk && tail_valid < KT) {                  // rare, wave-uniform: keys past the chunk's end
+      int tv = tail_valid - 4 * hi;
+      asm volatile("" : "+v"(tv));                           // (the 32 lane masks are computed here, not held in 64 SGPRs across the loop)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((r & 3) + 8 * (r >> 2) >= tv) scc[0][r] = -INFINITY;
+        if (32 + (r & 3) + 8 * (r >> 2) >= tv) scc[1][r] = -INFINITY;
+      }
+    }
+    X_FENCE();
+    p_pv(o[0], fr[0], pc, one);
+    if (!(ABL & 2)) stage_k();
+    fr[3] = v_frag(t + 7, 3);                     // V8T(t-1) fragment 3 ((t - 1) & 7 == (t + 7) & 7): the set K8(t) fragment 3 left at the end of the last tile
+#pragma unroll
+    for (int n = 0; n < 10; ++n) rm.step(n, scc[0], scc[1], hi);
+    X_FENCE();
+    p_pv(o[1], fr[1], pc, one);
+    if (!(ABL & 2)) stage_v();
+    fr[0] = k_frag(t + 1, 0);
+#pragma unroll
+    for (int n = 10; n < 20; ++n) rm.step(n, scc[0], scc[1], hi);
+    X_FENCE();
+    stamp(t, 2);
+    bool flag = false;
+    float alpha = 1.f;
+    if (first || __builtin_amdgcn_ballot_w64(rm.mx > P_SHIFT + DEFER_T) != 0) {     // rare: re-base
+      const float delta = first ? rm.mx - P_SHIFT : fmaxf(rm.mx - P_SHIFT, 0.f);
+      alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+      l_run *= alpha;
+      m_run += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { scc[0][r] -= delta; scc[1][r] -= delta; bs[r] = P_SHIFT - m_run; }
+      flag = true;                                   // O is scaled at the end of the tile: its P.V of tile t-1 is being issued now
+    }
+    es.init();
+    X_FENCE();
+    p_pv(o[2], fr[2], pc, one);
+    fr[1] = k_frag(t + 1, 1);
+    es_gap(0);
+    X_FENCE();
+    p_pv(o[3], fr[3], pc, one);
+    es_gap(1);
+    X_FENCE();
+    p_qk_first(scn[0], fr[0], qf[0], bs, one);
+    fr[2] = k_frag(t + 1, 2);
+    es_gap(2);
+    X_FENCE();
+    p_qk_first(scn[1], fr[1], qf[0], bs, one);
+    fr[3] = k_frag(t + 1, 3);
+    es_gap(3);
+    X_FENCE();
+    p_qk_acc(scn[0], fr[2], qf[1], one);
+    fr[0] = v_frag(t, 0);
+    es_gap(4);
+    X_FENCE();
+    p_qk_acc(scn[1], fr[3], qf[1], one);
+    fr[1] = v_frag(t, 1);
+    fr[2] = v_frag(t, 2);
+    es_gap(5);
+    X_FENCE();
+    stamp(t, 3);
+    l_run += es.total();
+    if (flag) {
+      o_settle();
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        asm volatile("" : "+v"(o[cb]));
+        X_FENCE();
+      }
+    }
+    if (!(ABL & 2)) stage_advance();
+  };
+
+  int t = 0;
+  for (; t + 1 < all_tiles; t += 2) {
+    iteration(t, sc[0], sc[1], pf[0], pf[1]);
+    iteration(t + 1, sc[1], sc[0], pf[1], pf[0]);
+  }
+  if (t < all_tiles) iteration(t, sc[0], sc[1], pf[0], pf[1]);
+  const bool odd = (all_tiles & 1) != 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]), "+v"(sc[1][1]));
+  fr[3] = v_frag(all_tiles - 1, 3);
+  {
+    const i32x8_t& plast = odd ? pf[1] : pf[0];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) p_pv(o[cb], fr[cb], plast, one);
+  }
+  o_settle();
+
+  float l = l_run;
+  l += other_half(l, hi);
+  if (MODE == 1) {
+    float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4_t*>(sp + cb * 32 + 8 * g + 4 * hi) = f32x4_t{o[cb][4 * g], o[cb][4 * g + 1], o[cb][4 * g + 2], o[cb][4 * g + 3]};
+    if (hi == 0) { sp[HD8] = m_run; sp[HD8 + 1] = l; }
+    return;
+  }
+  if (qrow < p.sq) {
+    const float inv = 1.f / l;
+    bf16_t* op = p.O + ((int64_t)seq * p.sq + qrow) * p.ldo + head * HD8;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x2_t w = {pack_bf2(o[cb][4 * g] * inv, o[cb][4 * g + 1] * inv), pack_bf2(o[cb][4 * g + 2] * inv, o[cb][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2_t*>(op + cb * 32 + 8 * g + 4 * hi) = w;
+      }
+  }
+}
+
 }  // namespace
 
 int am_attention_combine_launch(const am_attn_args* a, const float* part, int Z, int qblk_base, int rows, void* stream);   // am_attention.hip
@@ -1030,8 +1341,14 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   AM_CHECK(a->ldo % 4 == 0 && a->ldo >= a->heads * HD8, "am_attention_fp8: ldo=%d too small / misaligned", a->ldo);
   AM_CHECK((int64_t)HD8 * a->sk_pad * 1 < (1ll << 31), "am_attention_fp8: sk_pad too large for 32-bit lane offsets");
   const int abl = a->defer_log2 >= 5000 ? a->defer_log2 - 5000 : 0;     // 5000 + ABL: timing ablations (one-pass form only)
-  AM_CHECK(abl == 0 || (a->rows == 0 && a->state_mode == 0), "am_attention_fp8: ablation codes run the one-pass form only");
+  AM_CHECK(abl == 0 || abl == 200 || abl == 100 || (a->rows == 0 && a->state_mode == 0), "am_attention_fp8: ablation codes run the one-pass form only");
 #define F8_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
+#define X64_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8x64_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
+  AM_ONCE_PER_DEVICE({ X64_ATTR(0, 0); X64_ATTR(1, 0); X64_ATTR(2, 0); X64_ATTR(8, 0); X64_ATTR(0, 1); X64_ATTR(0, 2); });
+#undef X64_ATTR
+#define P_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
+  AM_ONCE_PER_DEVICE({ P_ATTR(0, 0); P_ATTR(1, 0); P_ATTR(2, 0); P_ATTR(8, 0); P_ATTR(0, 1); P_ATTR(0, 2); });
+#undef P_ATTR
   AM_ONCE_PER_DEVICE({ F8_ATTR(0, 0); F8_ATTR(1, 0); F8_ATTR(2, 0); F8_ATTR(4, 0); F8_ATTR(8, 0); F8_ATTR(16, 0); F8_ATTR(17, 0); F8_ATTR(6, 0);
                        F8_ATTR(32, 0); F8_ATTR(64, 0); F8_ATTR(40, 0); F8_ATTR(0, 1); F8_ATTR(0, 2); F8_ATTR(0, 3); });
 #undef F8_ATTR
@@ -1055,11 +1372,46 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   const bool split = tail_geom && all_tiles >= 4 * F8_SPLIT_Z && need * sizeof(float) <= (256u << 20);
   const int nblk_main = tail_geom ? nblk - 1 : nblk;
 #define F8_LAUNCH(A, M, GRID) hipLaunchKernelGGL((attn_fp8_kernel<A, M>), GRID, dim3(512), NSTAGE * STAGE_BYTES, st, p)
-  if (a->rows != 2) {                       // the main grid
+#define X64_LAUNCH(A, M, GRID) hipLaunchKernelGGL((attn_fp8x64_kernel<A, M>), GRID, dim3(256), NSTAGE * STAGE_BYTES, st, p, (unsigned long long*)nullptr)
+  // Product kernel of the main grid: the 4 x 64 form (round 4) for key streams of at least 8 tiles; defer_log2 = 5100 + ABL selects its
+  // timing ablations, 5200 forces the 8-wave kernel (same-box A/B, tests), 5000 + ABL are the 8-wave kernel's ablations as before.
+  const bool want8 = a->defer_log2 == 5200 || (abl != 0 && abl < 100);
+  const bool want64 = abl >= 100 && abl < 200;              // 5100 + ABL: the 4 x 64 form (measured 12 % slower: kept for the A/B)
+  const int xabl = want64 ? abl - 100 : 0;
+  const int pabl = abl >= 300 && abl < 400 ? abl - 300 : 0; // 5300 + ABL: timing ablations of the product (free-running) kernel
+  const bool long_stream = all_tiles >= 8 && getenv("ACTIONMESH_AMD_FP8_8WAVE") == nullptr;
+  const bool use_x64 = want64 && long_stream;
+  const bool use_p = !want8 && !want64 && long_stream;
+#define P_LAUNCH(A, M, GRID) hipLaunchKernelGGL((attn_fp8p_kernel<A, M>), GRID, dim3(512), NSTAGE * STAGE_BYTES, st, p, (unsigned long long*)nullptr)
+  if (a->rows != 2 && use_p) {
+    const dim3 grid(nblk_main, bh);
+    if (a->state_mode == 1) P_LAUNCH(0, 1, grid);
+    else if (a->state_mode == 2) P_LAUNCH(0, 2, grid);
+    else switch (pabl) {
+      case 0: P_LAUNCH(0, 0, grid); break;
+      case 1: P_LAUNCH(1, 0, grid); break;
+      case 2: P_LAUNCH(2, 0, grid); break;
+      case 8: P_LAUNCH(8, 0, grid); break;
+      default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
+    }
+  } else
+#undef P_LAUNCH
+  if (a->rows != 2 && use_x64) {
+    const dim3 grid(nblk_main, bh);
+    if (a->state_mode == 1) X64_LAUNCH(0, 1, grid);
+    else if (a->state_mode == 2) X64_LAUNCH(0, 2, grid);
+    else switch (xabl) {
+      case 0: X64_LAUNCH(0, 0, grid); break;
+      case 1: X64_LAUNCH(1, 0, grid); break;
+      case 2: X64_LAUNCH(2, 0, grid); break;
+      case 8: X64_LAUNCH(8, 0, grid); break;
+      default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown 4x64 ablation code %d", a->defer_log2);
+    }
+  } else if (a->rows != 2) {                       // the main grid
     const dim3 grid(nblk_main, bh);
     if (a->state_mode == 1) F8_LAUNCH(0, 1, grid);
     else if (a->state_mode == 2) F8_LAUNCH(0, 2, grid);
-    else switch (abl) {
+    else switch (abl == 200 ? 0 : abl) {
       case 0: F8_LAUNCH(0, 0, grid); break;
       case 1: F8_LAUNCH(1, 0, grid); break;
       case 2: F8_LAUNCH(2, 0, grid); break;
@@ -1093,6 +1445,41 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
     }
   }
 #undef F8_LAUNCH
+#undef X64_LAUNCH
   AM_HIP(hipGetLastError());
   return AM_OK;
 }
+
+#ifdef AM_ATTN_ABLATIONS
+extern "C" int am_attention_fp8p_profile(const am_attn_args* a, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8,
+                                         unsigned long long* prof_dev, void* stream) {
+  AM_TRY(check_args(a, "am_attention_fp8p_profile"));
+  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             NSTAGE * STAGE_BYTES));
+  f8_args p;
+  p.Q = q8; p.K = k8; p.Vt = vt8; p.O = a->O;
+  p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;
+  p.nchunks = a->nchunks; p.tiles_per_chunk = (a->sk + KT - 1) / KT; p.ldo = a->ldo;
+  p.chunk_stride = 0; p.chunk_first = 0; p.chunk_total = 0; p.qblk_base = 0; p.state = nullptr; p.part = nullptr;
+  hipLaunchKernelGGL((attn_fp8p_kernel<0, 0, true>), dim3((a->sq + 255) / 256, a->nseq * a->heads), dim3(512), NSTAGE * STAGE_BYTES,
+                     (hipStream_t)stream, p, prof_dev);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+// per-phase s_memtime stamps of workgroup (0,0) of the 4 x 64 kernel: prof[4 waves][8 tiles (64..71)][8 slots]  (tools/attn_profile.py --fp8x64)
+extern "C" int am_attention_fp8x64_profile(const am_attn_args* a, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8,
+                                           unsigned long long* prof_dev, void* stream) {
+  AM_TRY(check_args(a, "am_attention_fp8x64_profile"));
+  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8x64_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             NSTAGE * STAGE_BYTES));
+  f8_args p;
+  p.Q = q8; p.K = k8; p.Vt = vt8; p.O = a->O;
+  p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;
+  p.nchunks = a->nchunks; p.tiles_per_chunk = (a->sk + KT - 1) / KT; p.ldo = a->ldo;
+  p.chunk_stride = 0; p.chunk_first = 0; p.chunk_total = 0; p.qblk_base = 0; p.state = nullptr; p.part = nullptr;
+  hipLaunchKernelGGL((attn_fp8x64_kernel<0, 0, true>), dim3((a->sq + 255) / 256, a->nseq * a->heads), dim3(256), NSTAGE * STAGE_BYTES,
+                     (hipStream_t)stream, p, prof_dev);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+#endif

@@ -14,6 +14,46 @@ a = L.AmAttnArgs()
 a.Q, a.K, a.Vt, a.O = Q.data_ptr(), K.data_ptr(), Vt.data_ptr(), out.data_ptr()
 a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = B, H, S, Q.shape[2], S, K.shape[2]
 a.nchunks = 1; a.chunk_stride = 0; a.ldo = H * 128; a.scale = 128 ** -0.5; a.defer_log2 = 8
+if "--fp8p" in sys.argv:            # round 4: the free-running 8-wave fp8 kernel (product); needs tools/build_fp8_prof.sh + ACTIONMESH_AMD_LIB
+    ops.attention_fp8(Q, K, Vt, S, S, out=out)
+    q8, k8, vt8 = ops.attention_fp8.last_quantized
+    prof = torch.zeros(8 * 8 * 8, dtype=torch.int64, device=dev)
+    lib = C.CDLL(L.LIB_PATH)
+    lib.am_attention_fp8p_profile.argtypes = [C.POINTER(L.AmAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for _ in range(2):
+        rc = lib.am_attention_fp8p_profile(C.byref(a), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), prof.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    p = prof.cpu().view(8, 8, 8)
+    print("fp8 free-running kernel, workgroup (0,0), cycles (s_memtime): barrier wait | a (2 PV, 2 DMA, row max) | b (2 PV + 4 QK, exp/sum/pack) | tail")
+    for w in range(8):
+        print(f"wave {w}:")
+        for t in range(0, 7):
+            r = p[w, t]; nxt = p[w, t + 1, 0]
+            print(f"  tile {64 + t}: barrier {int(r[1]-r[0]):5d} | a {int(r[2]-r[1]):5d} | b {int(r[3]-r[2]):5d} | tail {int(nxt-r[3]):4d} | total {int(nxt-r[0]):5d}")
+    print("barrier-exit skew (tile 66):", [int(p[w, 2, 1] - p[0, 2, 1]) for w in range(8)])
+    sys.exit(0)
+if "--fp8x64" in sys.argv:          # round 4: the 4 x 64 fp8 kernel (needs tools/build_fp8_prof.sh + ACTIONMESH_AMD_LIB)
+    ops.attention_fp8(Q, K, Vt, S, S, out=out)
+    q8, k8, vt8 = ops.attention_fp8.last_quantized
+    prof = torch.zeros(4 * 8 * 8, dtype=torch.int64, device=dev)
+    lib = C.CDLL(L.LIB_PATH)
+    lib.am_attention_fp8x64_profile.argtypes = [C.POINTER(L.AmAttnArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for _ in range(2):
+        rc = lib.am_attention_fp8x64_profile(C.byref(a), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr(), prof.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    p = prof.cpu().view(4, 8, 8)
+    print("fp8 4x64 kernel, workgroup (0,0), cycles (s_memtime): barrier wait | 1a (2 PV, 2 DMA, row max 0) | 1b (6 PV, exp/sum/pack 0) | "
+          "2a (2 QK, 2 DMA, row max 1) | 2b (6 QK, exp/sum/pack 1) | tail")
+    for w in range(4):
+        print(f"wave {w}:")
+        for t in range(0, 7):
+            r = p[w, t]; nxt = p[w, t + 1, 0]
+            print(f"  tile {64 + t}: barrier {int(r[1]-r[0]):5d} | 1a {int(r[2]-r[1]):5d} | 1b {int(r[3]-r[2]):5d} | 2a {int(r[4]-r[3]):5d} | "
+                  f"2b {int(r[5]-r[4]):5d} | tail {int(nxt-r[5]):4d} | total {int(nxt-r[0]):5d}")
+    print("barrier-exit skew (tile 66):", [int(p[w, 2, 1] - p[0, 2, 1]) for w in range(4)])
+    sys.exit(0)
 if "--k64" in sys.argv:
     if "--exact" in sys.argv:
         a.defer_log2 = 28

@@ -66,6 +66,14 @@ def main():
             qz = ops.attention_fp8.last_quantized
             ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz), a.reps)
             print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (attend only)        : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        if not a.product_only or a.fp8:           # round 4: the 4 x 64 product kernel against the round-3 8-wave kernel, interleaved
+            for rnd_i in range(2):
+                for k, nm in ((0, "free-running 8w (product)"), (200, "ping-pong 8w (round 3)"), (100, "4x64")):
+                    ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
+                    print(f"  fp8 attend only, {nm:26s} round {rnd_i}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+            for k, nm in ((301, "product, no exp"), (302, "product, no LDS-DMA"), (308, "product, no softmax steps"), (101, "4x64 no exp"), (108, "4x64 no softmax steps")):
+                ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
+                print(f"  fp8 ablation {nm:24s}: {ms:8.3f} ms")
         if a.ablate_fp8:
             qz = ops.attention_fp8.last_quantized
             for k, nm in {1: "no exp", 16: "no row max", 17: "no exp, no row max", 2: "no LDS-DMA", 4: "no fragment reads", 6: "no DMA, no reads", 8: "no MFMAs", 32: "no s_setprio (full kernel)", 64: "s_setprio 1 on the softmax interval (full)", 40: "no setprio, no MFMAs"}.items():

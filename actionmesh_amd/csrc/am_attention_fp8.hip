@@ -1002,7 +1002,59 @@ __device__ __forceinline__ void p_qk_first(f32x16_t& d, const i32x8_t& k, const 
 __device__ __forceinline__ void p_qk_acc(f32x16_t& d, const i32x8_t& k, const i32x8_t& q, int one) {
   asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(k), "v"(q), "v"(one) : "memory");
 }
-template <int ABL, int MODE, bool PROF = false>
+// exp2 + e4m3 pack of one 16-score register set as single-instruction steps (the row sums are NOT here: they run on the matrix pipe,
+// l += ones x P^T, from the ROUNDED probabilities).  FAST = 0: 16 v_exp_f32 + 8 v_cvt_pk_fp8_f32, each pack a round behind its
+// exponentials.  FAST = 1 (attn_dtype "fp8_fast"): the scores are born as z = 8 (s - m_run + 5) + 56 and ONE v_cvt_pk_u8_f32 per score
+// (round to nearest even, saturating at 0) writes the e4m3 BYTE whose exponent field is floor(z / 8) and whose mantissa is z mod 8:
+// p = 2^n (1 + f) instead of 2^(n + f) - the exponential interpolated linearly between powers of two (exact at integer scores, at most
+// 6.1 % high in between, the same function in the numerator and in the row sum).  No transcendental instruction at all.
+template <int ABL, int FAST>
+struct PHalf {
+  static constexpr int N = FAST ? 16 : 24;
+  // Step n as a TEMPLATE parameter: every register / word index below is a constant at the first IR pass (with a run-time n the packed-P
+  // words were addressed through memory and stayed in scratch even after the loops had been unrolled).
+  // exact: steps 0, 1 = EX 0, EX 1; then for r = 1 .. 7: EX 2r, EX 2r+1, PK r-1; last: PK 7.   fast: step e = CV e.
+  template <int n>
+  __device__ __forceinline__ static void step(f32x16_t& s, i32x8_t& w, int half) {
+    if constexpr (FAST != 0) {
+      constexpr int word = n >> 2;
+      int x = half ? w[4 + word] : w[word];
+      if constexpr ((n & 3) == 0) asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(x) : "v"(s[n]));
+      else if constexpr ((n & 3) == 1) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(x) : "v"(s[n]));
+      else if constexpr ((n & 3) == 2) asm volatile("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(x) : "v"(s[n]));
+      else asm volatile("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(x) : "v"(s[n]));
+      if (half) w[4 + word] = x; else w[word] = x;
+    } else {
+      constexpr bool is_pk = n == 23 || (n >= 2 && (n - 2) % 3 == 2);
+      if constexpr (!is_pk) {
+        constexpr int e = n < 2 ? n : 2 * ((n - 2) / 3 + 1) + (n - 2) % 3;
+        float v = (ABL & 1) ? s[e] : __builtin_amdgcn_exp2f(s[e]);
+        X_PIN(v);
+        s[e] = v;
+      } else {                                     // pair pr = elements 2 pr, 2 pr + 1 -> half (pr & 1) of word 4 half + (pr >> 1)
+        constexpr int pr = n == 23 ? 7 : (n - 2) / 3;
+        constexpr int word = pr >> 1;
+        int x = half ? w[4 + word] : w[word];
+        if constexpr ((pr & 1) != 0) x = __builtin_amdgcn_cvt_pk_fp8_f32(s[2 * pr], s[2 * pr + 1], x, true);
+        else x = __builtin_amdgcn_cvt_pk_fp8_f32(s[2 * pr], s[2 * pr + 1], x, false);
+        X_PIN(x);
+        if (half) w[4 + word] = x; else w[word] = x;
+      }
+    }
+  }
+  template <int LO, int HI>
+  __device__ __forceinline__ static void run(f32x16_t& s, i32x8_t& w, int half) {
+    if constexpr (LO < HI) {
+      step<LO>(s, w, half);
+      run<LO + 1, HI>(s, w, half);
+    }
+  }
+};
+
+constexpr int P_LDS_ONES = NSTAGE * STAGE_BYTES;       // 2 KiB of e4m3 1.0 behind the ring: the A operand of the row-sum MFMA
+constexpr int P_LDS_BYTES = P_LDS_ONES + 2048;
+
+template <int ABL, int MODE, int FAST = 0, bool PROF = false>
 __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -1019,6 +1071,9 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
       if (lane == 0) prof[(wave * 8 + (t - 64)) * 8 + slot] = c;
     }
   };
+  // score units: u = SC (s - m_run + P_SHIFT) + OFF  (exact: log2 units; fast: eighths of an octave, biased so that u IS the e4m3 byte)
+  constexpr float SC = FAST ? 8.f : 1.f, OFF = FAST ? 56.f : 0.f;
+  constexpr float TOP = SC * P_SHIFT + OFF, THR = SC * (P_SHIFT + DEFER_T) + OFF;
 
   i32x8_t qf[2];
   {
@@ -1032,16 +1087,20 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
 #pragma unroll
     for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(qf[s]));
   }
-  f32x16_t o[4];
-  float m_run = P_SHIFT, l_run = 0.f;
+  f32x16_t o[4], lacc;                                       // lacc: every register = the row sum of this lane's query (ones x P^T)
+  float m_run = P_SHIFT;
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
   if (MODE == 2) {
     const float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
     m_run = sp[HD8];
-    l_run = hi == 0 ? sp[HD8 + 1] : 0.f;
+    const float l0 = sp[HD8 + 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = l0;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -1050,15 +1109,17 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[cb][4 * g + i] = t4[i];
       }
-    asm volatile("" : "+v"(m_run), "+v"(l_run));
+    asm volatile("" : "+v"(m_run));
   }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) asm volatile("" : "+v"(o[cb]));
+  asm volatile("" : "+v"(lacc));
   int one = SCALE_ONE;
-  asm volatile("" : "+v"(one));
+  int qk_scale = FAST ? 0x82828282 : SCALE_ONE;              // E8M0 2^3: the fast form's scores are born in eighths of an octave
+  asm volatile("" : "+v"(one), "+v"(qk_scale));
   f32x16_t bs;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) bs[r] = P_SHIFT - m_run;
+  for (int r = 0; r < 16; ++r) bs[r] = SC * (P_SHIFT - m_run) + OFF;
   X_PIN(bs);
 
   // ---- LDS-DMA: per tile every wave moves one 1 KiB piece of K8 (8 key rows) and one of V8T (16 channel rows)
@@ -1114,10 +1175,10 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     for (int e = 0; e < 2; ++e) k_off[s][e] = l31 * HD8 + (((4 * s + 2 * hi + e) ^ ksw) << 4);
 #pragma unroll
   for (int e = 0; e < 2; ++e) v_off[e] = 8192 + l31 * 64 + (((2 * hi + e) ^ vsw) << 4);
-  auto k_frag = [&](int tt, int n) __attribute__((always_inline)) {          // fragment n = (kb = n & 1, s = n >> 1)
-    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + (n & 1) * 32 * HD8;
-    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][0]);
-    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + k_off[n >> 1][1]);
+  auto k_frag = [&](int tt, int kb, int s2) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + kb * 32 * HD8;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + k_off[s2][0]);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + k_off[s2][1]);
     return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
   auto v_frag = [&](int tt, int cb) __attribute__((always_inline)) {
@@ -1126,36 +1187,57 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + v_off[1]);
     return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
+  auto ones_frag = [&]() __attribute__((always_inline)) {
+    const unsigned char* q = smem + P_LDS_ONES + lane * 32;
+    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(q);
+    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(q + 16);
+    return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
 
-  f32x16_t sc[2][2];           // ping-pong: S(t) in sc[cur], S(t+1) born in sc[cur ^ 1]
+  // Scores: the kb = 0 half (keys 0-31 of the tile) lives in ONE register set - its next tile's QK^T MFMAs are issued behind the last
+  // step that reads it - and only the kb = 1 half is a ping-pong pair: 48 registers instead of 64, which is what pays for lacc.
+  f32x16_t sa, sb[2];
   i32x8_t pf[2];               // P(t-1) in pf[cur] (being multiplied), P(t) born in pf[cur ^ 1]
-  i32x8_t fr[4];
+  i32x8_t fa, fb, fc;          // THREE rotating fragment sets for the 9 MFMAs of a tile: MFMA j reads set j % 3, refilled right behind it
   const i32x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   pf[0] = pf[1] = zero8;
   X_PIN(pf[0]); X_PIN(pf[1]);
   const int tail_valid = p.sk - (p.tiles_per_chunk - 1) * KT;
   int tic = 0;
 
-  // ---- prologue: tiles 0 .. 3 in flight; V8T of ring slot 7 zeroed ("V8T(-1)": P(-1) = 0, but stale LDS bytes may be NaN patterns)
+  // ---- prologue: tiles 0 .. 3 in flight; V8T of ring slot 7 zeroed ("V8T(-1)": P(-1) = 0, but stale LDS bytes may be NaN patterns);
+  // the block of ones
 #pragma unroll
   for (int a = 0; a < X_AHEAD; ++a) { stage_k(); stage_v(); stage_advance(); }
   *reinterpret_cast<u32x4_t*>(smem + 7 * STAGE_BYTES + 8192 + tid * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  *reinterpret_cast<uint32_t*>(smem + P_LDS_ONES + tid * 4) = 0x38383838u;
   asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // tile 0 (tiles 1 .. 3 = 6 pieces stay in flight)
-#pragma unroll
-  for (int n = 0; n < 4; ++n) fr[n] = k_frag(0, n);
-  p_qk_first(sc[0][0], fr[0], qf[0], bs, one);
-  p_qk_first(sc[0][1], fr[1], qf[0], bs, one);
-  p_qk_acc(sc[0][0], fr[2], qf[1], one);
-  p_qk_acc(sc[0][1], fr[3], qf[1], one);
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]));
-#pragma unroll
-  for (int n = 0; n < 4; ++n) { fr[n] = zero8; X_PIN(fr[n]); }
+  fa = k_frag(0, 0, 0); fb = k_frag(0, 1, 0); fc = k_frag(0, 0, 1);
+  {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&v"(sa) : "v"(fa), "v"(qf[0]), "v"(bs), "v"(qk_scale), "v"(one) : "memory");
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&v"(sb[0]) : "v"(fb), "v"(qf[0]), "v"(bs), "v"(qk_scale), "v"(one) : "memory");
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(sa) : "v"(fc), "v"(qf[1]), "v"(qk_scale), "v"(one) : "memory");
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fa), "+v"(fb), "+v"(fc));
+    fa = k_frag(0, 1, 1);
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(sb[0]) : "v"(fa), "v"(qf[1]), "v"(qk_scale), "v"(one) : "memory");
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fa));
+  }
+  fa = zero8; fb = zero8; fc = zero8;                      // "V8T(-1)" channel blocks 0 .. 2
+  X_PIN(fa); X_PIN(fb); X_PIN(fc);
 
-  auto o_settle = [&]() __attribute__((always_inline)) {
-    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+  auto qk_first = [&](f32x16_t& d, const i32x8_t& k) __attribute__((always_inline)) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(k), "v"(qf[0]), "v"(bs), "v"(qk_scale), "v"(one) : "memory");
   };
+  auto qk_acc = [&](f32x16_t& d, const i32x8_t& k) __attribute__((always_inline)) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(k), "v"(qf[1]), "v"(qk_scale), "v"(one) : "memory");
+  };
+  auto o_settle = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(lacc));
+  };
+  using Half = PHalf<ABL, FAST>;
+  constexpr int HN = Half::N;
 
-  auto iteration = [&](const int t, f32x16_t (&scc)[2], f32x16_t (&scn)[2], i32x8_t& pc, i32x8_t& pn) __attribute__((always_inline)) {
+  auto iteration = [&](const int t, f32x16_t& sbc, f32x16_t& sbn, i32x8_t& pc, i32x8_t& pn) __attribute__((always_inline)) {
     stamp(t, 0);
     asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");      // tile t+1 has landed everywhere (tiles t+2, t+3 in flight)
     stamp(t, 1);
@@ -1163,75 +1245,74 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
     tic = last_of_chunk ? 0 : tic + 1;
     XRowMax rm;
-    XExpSumPack<ABL> es;
-    constexpr XEsTab ES = x_es_tab(es.SEQ);
-    auto es_gap = [&](int gap) __attribute__((always_inline)) {
-      if (!(ABL & 8))
-#pragma unroll
-        for (int n = ES.lo[gap]; n < ES.lo[gap + 1]; ++n) es.step(n, scc[0], scc[1], pn);
-    };
+#define STEPS_A(G) do { if (!(ABL & 8)) Half::template run<HN * (G) / 4, HN * ((G) + 1) / 4>(sa, pn, 0); } while (0)      /* share G of 4 of the kb = 0 half */
+#define STEPS_B(G) do { if (!(ABL & 8)) Half::template run<HN * (G) / 3, HN * ((G) + 1) / 3>(sbc, pn, 1); } while (0)     /* share G of 3 of the kb = 1 half */
     if (last_of_chunk && tail_valid < KT) {                  // rare, wave-uniform: keys past the chunk's end
       int tv = tail_valid - 4 * hi;
-      asm volatile("" : "+v"(tv));                           // (the 32 lane masks are computed here, not held in 64 SGPRs across the loop)
+      asm volatile("" : "+v"(tv));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if ((r & 3) + 8 * (r >> 2) >= tv) scc[0][r] = -INFINITY;
-        if (32 + (r & 3) + 8 * (r >> 2) >= tv) scc[1][r] = -INFINITY;
+        if ((r & 3) + 8 * (r >> 2) >= tv) sa[r] = -INFINITY;
+        if (32 + (r & 3) + 8 * (r >> 2) >= tv) sbc[r] = -INFINITY;
       }
     }
+    // The four P.V MFMAs need nothing of this tile's softmax: they are issued first, so that they EXECUTE under the two LDS-DMA pieces
+    // (~150 cycles of issue stall each) and under the dependent row-max chain - the wave's own stalls are covered by its own MFMAs.
     X_FENCE();
-    p_pv(o[0], fr[0], pc, one);
+    p_pv(o[0], fa, pc, one);                      // j0
     if (!(ABL & 2)) stage_k();
-    fr[3] = v_frag(t + 7, 3);                     // V8T(t-1) fragment 3 ((t - 1) & 7 == (t + 7) & 7): the set K8(t) fragment 3 left at the end of the last tile
-#pragma unroll
-    for (int n = 0; n < 10; ++n) rm.step(n, scc[0], scc[1], hi);
+    fa = v_frag(t + 7, 3);                        // for j3: V8T(t-1) channel block 3  ((t - 1) & 7 == (t + 7) & 7)
     X_FENCE();
-    p_pv(o[1], fr[1], pc, one);
+    p_pv(o[1], fb, pc, one);                      // j1
     if (!(ABL & 2)) stage_v();
-    fr[0] = k_frag(t + 1, 0);
+    fb = ones_frag();                             // for j4
+    X_FENCE();
+    p_pv(o[2], fc, pc, one);                      // j2
+    fc = k_frag(t + 1, 1, 0);                     // for j5
 #pragma unroll
-    for (int n = 10; n < 20; ++n) rm.step(n, scc[0], scc[1], hi);
+    for (int n = 0; n < 10; ++n) rm.step(n, sa, sbc, hi);
+    X_FENCE();
+    p_pv(o[3], fa, pc, one);                      // j3
+    fa = k_frag(t + 1, 0, 0);                     // for j6
+#pragma unroll
+    for (int n = 10; n < 20; ++n) rm.step(n, sa, sbc, hi);
     X_FENCE();
     stamp(t, 2);
     bool flag = false;
     float alpha = 1.f;
-    if (first || __builtin_amdgcn_ballot_w64(rm.mx > P_SHIFT + DEFER_T) != 0) {     // rare: re-base
-      const float delta = first ? rm.mx - P_SHIFT : fmaxf(rm.mx - P_SHIFT, 0.f);
+    if (first || __builtin_amdgcn_ballot_w64(rm.mx > THR) != 0) {     // rare: re-base
+      const float du = first ? rm.mx - TOP : fmaxf(rm.mx - TOP, 0.f);
+      const float delta = du * (1.f / SC);
       alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-      l_run *= alpha;
       m_run += delta;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { scc[0][r] -= delta; scc[1][r] -= delta; bs[r] = P_SHIFT - m_run; }
-      flag = true;                                   // O is scaled at the end of the tile: its P.V of tile t-1 is being issued now
+      for (int r = 0; r < 16; ++r) { sa[r] -= du; sbc[r] -= du; bs[r] = SC * (P_SHIFT - m_run) + OFF; }
+      flag = true;                                   // O and l are scaled at the end of the tile: their MFMAs of tile t-1 are in flight
     }
-    es.init();
     X_FENCE();
-    p_pv(o[2], fr[2], pc, one);
-    fr[1] = k_frag(t + 1, 1);
-    es_gap(0);
+    p_pv(lacc, fb, pc, one);                      // j4: l += ones x P^T(t-1)
+    fb = k_frag(t + 1, 1, 1);                     // for j7
+    STEPS_A(0);
     X_FENCE();
-    p_pv(o[3], fr[3], pc, one);
-    es_gap(1);
+    qk_first(sbn, fc);                            // j5: keys 32-63 of tile t+1
+    fc = k_frag(t + 1, 0, 1);                     // for j8
+    STEPS_A(1);
+    STEPS_A(2);
+    STEPS_A(3);                                   // the kb = 0 half of S(t) is consumed
     X_FENCE();
-    p_qk_first(scn[0], fr[0], qf[0], bs, one);
-    fr[2] = k_frag(t + 1, 2);
-    es_gap(2);
+    qk_first(sa, fa);                             // j6: keys 0-31 of tile t+1, into the registers S(t) has just left
+    fa = v_frag(t, 0);                            // for the next tile's j0
+    STEPS_B(0);
     X_FENCE();
-    p_qk_first(scn[1], fr[1], qf[0], bs, one);
-    fr[3] = k_frag(t + 1, 3);
-    es_gap(3);
+    qk_acc(sbn, fb);                              // j7
+    fb = v_frag(t, 1);
+    STEPS_B(1);
     X_FENCE();
-    p_qk_acc(scn[0], fr[2], qf[1], one);
-    fr[0] = v_frag(t, 0);
-    es_gap(4);
-    X_FENCE();
-    p_qk_acc(scn[1], fr[3], qf[1], one);
-    fr[1] = v_frag(t, 1);
-    fr[2] = v_frag(t, 2);
-    es_gap(5);
+    qk_acc(sa, fc);                               // j8
+    fc = v_frag(t, 2);
+    STEPS_B(2);
     X_FENCE();
     stamp(t, 3);
-    l_run += es.total();
     if (flag) {
       o_settle();
 #pragma unroll
@@ -1241,29 +1322,41 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
         asm volatile("" : "+v"(o[cb]));
         X_FENCE();
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+      asm volatile("" : "+v"(lacc));
+      X_FENCE();
     }
     if (!(ABL & 2)) stage_advance();
+#undef STEPS_A
+#undef STEPS_B
   };
 
   int t = 0;
   for (; t + 1 < all_tiles; t += 2) {
-    iteration(t, sc[0], sc[1], pf[0], pf[1]);
-    iteration(t + 1, sc[1], sc[0], pf[1], pf[0]);
+    iteration(t, sb[0], sb[1], pf[0], pf[1]);
+    iteration(t + 1, sb[1], sb[0], pf[1], pf[0]);
   }
-  if (t < all_tiles) iteration(t, sc[0], sc[1], pf[0], pf[1]);
+  if (t < all_tiles) iteration(t, sb[0], sb[1], pf[0], pf[1]);
   const bool odd = (all_tiles & 1) != 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]), "+v"(sc[1][1]));
-  fr[3] = v_frag(all_tiles - 1, 3);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sa), "+v"(sb[0]), "+v"(sb[1]));
   {
-    const i32x8_t& plast = odd ? pf[1] : pf[0];
+    i32x8_t plast;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) p_pv(o[cb], fr[cb], plast, one);
+    for (int e = 0; e < 8; ++e) plast[e] = odd ? pf[1][e] : pf[0][e];       // by value: a select between two ADDRESSES keeps pf in memory
+    p_pv(o[0], fa, plast, one);
+    p_pv(o[1], fb, plast, one);
+    p_pv(o[2], fc, plast, one);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(fa), "+v"(fb));
+    fa = v_frag(all_tiles - 1, 3);
+    fb = ones_frag();
+    p_pv(o[3], fa, plast, one);
+    p_pv(lacc, fb, plast, one);
   }
   o_settle();
 
-  float l = l_run;
-  l += other_half(l, hi);
+  const float l = lacc[0];
   if (MODE == 1) {
     float* sp = p.state + ((int64_t)sh * p.sq_pad + qrow) * F8_STATE_LD;
 #pragma unroll
@@ -1341,13 +1434,13 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   AM_CHECK(a->ldo % 4 == 0 && a->ldo >= a->heads * HD8, "am_attention_fp8: ldo=%d too small / misaligned", a->ldo);
   AM_CHECK((int64_t)HD8 * a->sk_pad * 1 < (1ll << 31), "am_attention_fp8: sk_pad too large for 32-bit lane offsets");
   const int abl = a->defer_log2 >= 5000 ? a->defer_log2 - 5000 : 0;     // 5000 + ABL: timing ablations (one-pass form only)
-  AM_CHECK(abl == 0 || abl == 200 || abl == 100 || (a->rows == 0 && a->state_mode == 0), "am_attention_fp8: ablation codes run the one-pass form only");
+  AM_CHECK(abl == 0 || abl == 200 || abl == 100 || abl == 400 || (a->rows == 0 && a->state_mode == 0), "am_attention_fp8: ablation codes run the one-pass form only");
 #define F8_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
 #define X64_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8x64_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
   AM_ONCE_PER_DEVICE({ X64_ATTR(0, 0); X64_ATTR(1, 0); X64_ATTR(2, 0); X64_ATTR(8, 0); X64_ATTR(0, 1); X64_ATTR(0, 2); });
 #undef X64_ATTR
-#define P_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES))
-  AM_ONCE_PER_DEVICE({ P_ATTR(0, 0); P_ATTR(1, 0); P_ATTR(2, 0); P_ATTR(8, 0); P_ATTR(0, 1); P_ATTR(0, 2); });
+#define P_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES))
+  AM_ONCE_PER_DEVICE({ P_ATTR(0, 0, 0); P_ATTR(1, 0, 0); P_ATTR(2, 0, 0); P_ATTR(8, 0, 0); P_ATTR(0, 1, 0); P_ATTR(0, 2, 0); P_ATTR(0, 0, 1); P_ATTR(0, 1, 1); P_ATTR(0, 2, 1); });
 #undef P_ATTR
   AM_ONCE_PER_DEVICE({ F8_ATTR(0, 0); F8_ATTR(1, 0); F8_ATTR(2, 0); F8_ATTR(4, 0); F8_ATTR(8, 0); F8_ATTR(16, 0); F8_ATTR(17, 0); F8_ATTR(6, 0);
                        F8_ATTR(32, 0); F8_ATTR(64, 0); F8_ATTR(40, 0); F8_ATTR(0, 1); F8_ATTR(0, 2); F8_ATTR(0, 3); });
@@ -1379,19 +1472,24 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   const bool want64 = abl >= 100 && abl < 200;              // 5100 + ABL: the 4 x 64 form (measured 12 % slower: kept for the A/B)
   const int xabl = want64 ? abl - 100 : 0;
   const int pabl = abl >= 300 && abl < 400 ? abl - 300 : 0; // 5300 + ABL: timing ablations of the product (free-running) kernel
+  const bool fast = abl == 400;                             // 5400: the exponent-field form of the probabilities (attn_dtype "fp8_fast")
   const bool long_stream = all_tiles >= 8 && getenv("ACTIONMESH_AMD_FP8_8WAVE") == nullptr;
   const bool use_x64 = want64 && long_stream;
   const bool use_p = !want8 && !want64 && long_stream;
-#define P_LAUNCH(A, M, GRID) hipLaunchKernelGGL((attn_fp8p_kernel<A, M>), GRID, dim3(512), NSTAGE * STAGE_BYTES, st, p, (unsigned long long*)nullptr)
+#define P_LAUNCH(A, M, F, GRID) hipLaunchKernelGGL((attn_fp8p_kernel<A, M, F>), GRID, dim3(512), P_LDS_BYTES, st, p, (unsigned long long*)nullptr)
   if (a->rows != 2 && use_p) {
     const dim3 grid(nblk_main, bh);
-    if (a->state_mode == 1) P_LAUNCH(0, 1, grid);
-    else if (a->state_mode == 2) P_LAUNCH(0, 2, grid);
+    if (fast) {
+      if (a->state_mode == 1) P_LAUNCH(0, 1, 1, grid);
+      else if (a->state_mode == 2) P_LAUNCH(0, 2, 1, grid);
+      else P_LAUNCH(0, 0, 1, grid);
+    } else if (a->state_mode == 1) P_LAUNCH(0, 1, 0, grid);
+    else if (a->state_mode == 2) P_LAUNCH(0, 2, 0, grid);
     else switch (pabl) {
-      case 0: P_LAUNCH(0, 0, grid); break;
-      case 1: P_LAUNCH(1, 0, grid); break;
-      case 2: P_LAUNCH(2, 0, grid); break;
-      case 8: P_LAUNCH(8, 0, grid); break;
+      case 0: P_LAUNCH(0, 0, 0, grid); break;
+      case 1: P_LAUNCH(1, 0, 0, grid); break;
+      case 2: P_LAUNCH(2, 0, 0, grid); break;
+      case 8: P_LAUNCH(8, 0, 0, grid); break;
       default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
     }
   } else
@@ -1454,14 +1552,14 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
 extern "C" int am_attention_fp8p_profile(const am_attn_args* a, const uint8_t* q8, const uint8_t* k8, const uint8_t* vt8,
                                          unsigned long long* prof_dev, void* stream) {
   AM_TRY(check_args(a, "am_attention_fp8p_profile"));
-  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             NSTAGE * STAGE_BYTES));
+  AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<0, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             P_LDS_BYTES));
   f8_args p;
   p.Q = q8; p.K = k8; p.Vt = vt8; p.O = a->O;
   p.heads = a->heads; p.sq = a->sq; p.sq_pad = a->sq_pad; p.sk = a->sk; p.sk_pad = a->sk_pad;
   p.nchunks = a->nchunks; p.tiles_per_chunk = (a->sk + KT - 1) / KT; p.ldo = a->ldo;
   p.chunk_stride = 0; p.chunk_first = 0; p.chunk_total = 0; p.qblk_base = 0; p.state = nullptr; p.part = nullptr;
-  hipLaunchKernelGGL((attn_fp8p_kernel<0, 0, true>), dim3((a->sq + 255) / 256, a->nseq * a->heads), dim3(512), NSTAGE * STAGE_BYTES,
+  hipLaunchKernelGGL((attn_fp8p_kernel<0, 0, 0, true>), dim3((a->sq + 255) / 256, a->nseq * a->heads), dim3(512), P_LDS_BYTES,
                      (hipStream_t)stream, p, prof_dev);
   AM_HIP(hipGetLastError());
   return AM_OK;

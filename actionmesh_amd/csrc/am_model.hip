@@ -247,7 +247,7 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
   AM_CHECK(cfg->world_size >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world_size, "am_create: rank %d / world %d",
            cfg->rank, cfg->world_size);
   AM_CHECK(cfg->attn_defer_log2 == 0 || cfg->attn_defer_log2 == 8, "am_create: attn_defer_log2 must be 0 or 8");
-  AM_CHECK(cfg->attn_fp8 == 0 || cfg->attn_fp8 == 1, "am_create: attn_fp8 must be 0 or 1");
+  AM_CHECK(cfg->attn_fp8 >= 0 && cfg->attn_fp8 <= 2, "am_create: attn_fp8 must be 0 (bf16), 1 (fp8) or 2 (fp8, exponent-field probabilities)");
   int ndev = 0;
   AM_HIP(hipGetDeviceCount(&ndev));
   AM_CHECK(ndev > 0, "am_create: no HIP device visible (this library has no CPU path)");
@@ -603,6 +603,7 @@ extern "C" int am_layer_attn_local(am_handle h, int i, void* stream) {
   at.nchunks = 1; at.chunk_first = h->rank; at.chunk_total = h->P;
   if (h->cfg.attn_fp8) {                       // never a silent bf16 pass on an fp8 handle
     at.chunk_stride = (int64_t)h->chunk_stride8;
+    if (h->cfg.attn_fp8 == 2) at.defer_log2 = 5400;      /* the exponent-field form of the probabilities (am_attention_fp8) */
     AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, stream));
     ++h->n_attn_fp8;
   } else {
@@ -657,9 +658,11 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     }
     if (h->cfg.attn_fp8) {
       at.chunk_stride = rest.chunk_stride = (int64_t)h->chunk_stride8;
+      if (h->cfg.attn_fp8 == 2) at.defer_log2 = 5400;      /* the exponent-field form of the probabilities (am_attention_fp8) */
       AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
       TR(10, i, h->ao, (size_t)Rs * C * 2);
       rest.rows = 2;
+      if (h->cfg.attn_fp8 == 2) rest.defer_log2 = 5400;      /* the exponent-field form of the probabilities (am_attention_fp8) */
       AM_TRY(am_attention_fp8(&rest, h->Q8, h->K8, h->Vt8, st));
     } else {
       AM_TRY(am_attention_bf16(&at, st));
@@ -679,6 +682,7 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     if (shared) at.nseq /= h->B;                           // row 0's sequences only (they come first in every layout)
     if (h->cfg.attn_fp8 && h->inflated(i)) {       // fp8 variant of the long-key-stream attention (configs[4]); operands quantised in pre
       at.chunk_stride = (int64_t)h->chunk_stride8;
+      if (h->cfg.attn_fp8 == 2) at.defer_log2 = 5400;      /* the exponent-field form of the probabilities (am_attention_fp8) */
       AM_TRY(am_attention_fp8(&at, h->Q8, h->K8, h->Vt8, st));
       ++h->n_attn_fp8;
     } else {

@@ -107,9 +107,9 @@ class HipEngine:
         cfg.max_batch, cfg.max_frames_local, cfg.max_tokens, cfg.max_ctx_tokens = self.bounds
         cfg.world_size, cfg.rank = world, rank
         cfg.attn_defer_log2 = attn_defer_log2
-        if attn_dtype not in ("bf16", "fp8"):
-            raise ValueError(f"attn_dtype must be 'bf16' or 'fp8', got {attn_dtype!r}")
-        cfg.attn_fp8 = 1 if attn_dtype == "fp8" else 0
+        if attn_dtype not in ("bf16", "fp8", "fp8_fast"):
+            raise ValueError(f"attn_dtype must be 'bf16', 'fp8' or 'fp8_fast', got {attn_dtype!r}")
+        cfg.attn_fp8 = {"bf16": 0, "fp8": 1, "fp8_fast": 2}[attn_dtype]
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self.lib.am_create(C.byref(cfg), C.byref(self.handle)), "am_create")
@@ -130,7 +130,7 @@ class HipEngine:
                 L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
                 # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands.  An fp8 handle
                 # exchanges the QUANTISED shards (am_bind_kv8_buffers): one byte per element, half the traffic.
-                esz = 1 if attn_dtype == "fp8" else 2
+                esz = 1 if attn_dtype.startswith("fp8") else 2
                 if kv_factory is not None:      # copy-engine back-end: the buffer is an IPC-shared hipMalloc, not a torch tensor
                     self.exchange = kv_factory(2 * n.value * esz)
                     base = self.exchange.kv_ptr()

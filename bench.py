@@ -113,7 +113,12 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
     Vt = torch.randn((fw, B, H, 128, sk_pad), device=dev, generator=g).to(torch.bfloat16)
     out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=dev)
     flops = 4.0 * Sq * (Sq * fw) * (H * 128) * B
+    fast = dtype == "fp8_fast"
+    if fast:
+        dtype = "fp8"
     attn = ops.attention_fp8 if dtype == "fp8" else ops.attention
+    if fast:
+        attn = lambda *a, **k: ops.attention_fp8(*a, ablate=400, **k)        # the exponent-field probabilities (attn_dtype "fp8_fast")
     peak = PEAK_FP8_TFLOPS if dtype == "fp8" else PEAK_BF16_TFLOPS
 
     def sample(qscale, K=K, Vt=Vt):
@@ -149,7 +154,7 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
             if rec.get("shape") == [T, N, H] and rec.get("source_sha") == source_sha():
                 traffic, traffic_src = rec.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(tj)
                 break
-    name = "attn_fwd64_kernel" if dtype == "bf16" else "attn_fp8_kernel"
+    name = "attn_fwd64_kernel" if dtype == "bf16" else ("attn_fp8p_kernel<FAST=1>" if fast else "attn_fp8p_kernel")
     return {"bound": "mfma", "kernel": f"{name} (inflated self-attention, 1 launch = 1 layer on this rank; timed with its "
                                        "exact-fallback grid and split-tail kernels)",
             "achieved": plain["achieved"], "peak": peak, "unit": "TFLOP/s",
@@ -315,7 +320,7 @@ def emulate_world(P, shape, dtype, dev, steps=3):
     torch.cuda.synchronize(dev)
     sec = (time.perf_counter() - t0) / steps
     L = N + 1
-    shard_bytes = bl * tl * L * C * 2 * (1 if dtype == "fp8" else 2)
+    shard_bytes = bl * tl * L * C * 2 * (1 if dtype.startswith("fp8") else 2)
     link_ms = shard_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if fw > 1 else 0.0
     n8, n16 = eng.attention_counters()
     eng.close()
@@ -369,10 +374,11 @@ def main():
     ap.add_argument("--shape", default="headline", choices=list(SHAPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8", "fp8_fast"],
                     help="fp8: the inflated self-attention (QK^T, P.V) on the e4m3 MX-scaled MFMA kernel - BASELINE.json "
                          "configs[4] (use with --shape long64); GEMMs, norms and the residual stream stay bf16.  The headline "
-                         "metric is bf16.")
+                         "metric is bf16.  fp8_fast: the same with the exponent-field form of the probabilities (no v_exp; reported "
+                         "as dtype fp8 with `attention_probabilities` saying so)")
     ap.add_argument("--graph", action="store_true", help="single GPU: the forward through a captured HIP graph (am_denoise_forward_graph)")
     ap.add_argument("--emulate-world", type=int, default=0, metavar="P", help="single GPU only: print a PROJECTION record instead - rank 0's share of "
                     "a step of a P-rank run timed on this device, beside the modelled xGMI time of the per-layer exchange")
@@ -493,7 +499,7 @@ def main():
     # the arithmetic type the inflated self-attention REALLY ran in (am_attention_counters), not the one that was asked for
     n_fp8, n_bf16 = model._engine.attention_counters()
     ran = "fp8" if (n_fp8 > 0 and n_bf16 == 0) else "bf16" if n_fp8 == 0 else f"mixed (fp8 x{n_fp8}, bf16 x{n_bf16})"
-    if ran != args.dtype:
+    if ran != ("fp8" if args.dtype.startswith("fp8") else args.dtype):
         raise SystemExit(f"bench.py: --dtype {args.dtype} was requested but the engine's self-attention ran in {ran}")
     result = {
         "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
@@ -511,6 +517,8 @@ def main():
         "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
         "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if ran == "fp8" else PEAK_BF16_TFLOPS), 4),
         "attention_launches": {"fp8": n_fp8, "bf16": n_bf16},
+        "attention_probabilities": ("exponent-field e4m3 bytes, p = 2^n (1 + f) (fp8_fast: no transcendental instruction)" if args.dtype == "fp8_fast"
+                                    else "exp2, rounded to e4m3" if ran == "fp8" else "exp2, rounded to bf16"),
         # second half of BASELINE.json's metric: needs the pretrained checkpoints (facebook/ActionMesh, TripoSG, RMBG) and a
         # real video, none reachable offline - not measured here, and nothing in `value` stands in for it
         "with_exact_shortcuts": {"ms_per_step": round(elapsed2 / args.steps * 1e3, 2), "value": round(args.steps / elapsed2, 4),
@@ -525,7 +533,7 @@ def main():
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
     }
     if rank == 0 and not args.no_roofline:
-        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=ran)
+        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=args.dtype)
     if rank == 0 and world == 1:
         del model
         torch.cuda.empty_cache()

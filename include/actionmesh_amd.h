@@ -68,7 +68,8 @@ typedef struct {
   int32_t world_size;           /* frame-shard degree P (1 = single GPU) */
   int32_t rank;                 /* this rank's shard index */
   int32_t attn_defer_log2;      /* online-softmax deferred-rescale threshold (log2 units); 0 = always rescale */
-  int32_t attn_fp8;             /* 1 = inflated self-attention on the fp8 kernel (am_attention_fp8); 0 = bf16 (default) */
+  int32_t attn_fp8;             /* 1 = inflated self-attention on the fp8 kernel (am_attention_fp8); 0 = bf16 (default); 2 = fp8 with the
+                                   exponent-field form of the probabilities (no v_exp: p = 2^n (1 + f), am_attention_fp8 defer_log2 = 5400) */
   int32_t reserved[6];
 } am_config;
 

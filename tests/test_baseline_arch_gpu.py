@@ -90,20 +90,20 @@ K8, EPS8 = 1.15, 2e-3
 
 
 def tol_curve(dtype, ref, step=None):
-    if dtype == "fp8":
+    if dtype.startswith("fp8"):          # fp8_fast (exponent-field probabilities): held to the same statement, measured in profiles/r04h_*
         return K8 * ref + EPS8
     return 1.15 * ref + 2e-3
 
 
 def tol_cap(dtype, step):
-    return tol_plain(step) * (K8 / 1.15 if dtype == "fp8" else 1.0)
+    return tol_plain(step) * (K8 / 1.15 if dtype.startswith("fp8") else 1.0)
 
 
 def _tag(name, dtype):
     return name if dtype == "bf16" else f"{name}_{dtype}"
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8_fast"])
 @pytest.mark.parametrize("name", ["full_headline", "full_nominal"])
 def test_full_shape_forward(dev, golden_dir, name, dtype):
     """ONE forward at the FULL benchmarked shapes (VERDICT r02 missing #2) against the reference's own modules: the headline workload
@@ -118,7 +118,7 @@ def test_full_shape_forward(dev, golden_dir, name, dtype):
     stride = int(g["token_stride"])
     v = _forward(model, inp, float(g["fwd_t"]), dev)
     n8, n16 = model._engine.attention_counters()
-    assert (n8 > 0 and n16 == 0) if dtype == "fp8" else (n8 == 0 and n16 > 0), (dtype, n8, n16)      # the arithmetic that really ran
+    assert (n8 > 0 and n16 == 0) if dtype.startswith("fp8") else (n8 == 0 and n16 > 0), (dtype, n8, n16)      # the arithmetic that really ran
     model.cpu()
     ref = torch.from_numpy(g["fwd_velocity_fp32_sub"])
     got = v[:, :, ::stride]
@@ -134,7 +134,7 @@ def test_full_shape_forward(dev, golden_dir, name, dtype):
     assert abs(float(v.double().pow(2).mean().sqrt()) - rms) < 2e-2 * rms
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8_fast"])
 @pytest.mark.parametrize("name", ["arch_headline", "arch_nominal", "arch_headline_50"])
 def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name, dtype):
     """bf16: the product path.  fp8: `attn_dtype="fp8"` - BASELINE configs[4]'s arithmetic - through the same 21-layer / depth-10-skip
@@ -167,7 +167,7 @@ def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name, dtype
     print(f"{name}: reference autocast(bf16) vs its fp32:       " + " ".join(f"{c:.2e}" for c in ref_curve))
     print(f"{name} [{dtype}]: final full latents rel-L2 {final:.3e}")
     n8, n16 = model._engine.attention_counters()
-    assert (n8 > 0 and n16 == 0) if dtype == "fp8" else (n8 == 0 and n16 > 0), (dtype, n8, n16)
+    assert (n8 > 0 and n16 == 0) if dtype.startswith("fp8") else (n8 == 0 and n16 > 0), (dtype, n8, n16)
     worst = max(c / float(ref_curve[i]) for i, c in enumerate(curve) if i < len(ref_curve) and i >= 2)
     _record(_tag(name, dtype), dict(forward=r_fwd, curve=curve, ref_autocast_curve=[float(c) for c in ref_curve], final=final,
                                     attn_dtype=dtype, worst_ratio_to_ref_autocast_from_step_3=worst))

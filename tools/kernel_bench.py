@@ -68,7 +68,7 @@ def main():
             print(f"self-attn  B={B} H={H} S={Sq} fp8 e4m3 (attend only)        : {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         if not a.product_only or a.fp8:           # round 4: the 4 x 64 product kernel against the round-3 8-wave kernel, interleaved
             for rnd_i in range(2):
-                for k, nm in ((0, "free-running 8w (product)"), (200, "ping-pong 8w (round 3)"), (100, "4x64")):
+                for k, nm in ((0, "free-running 8w (product)"), (400, "same, exponent-field P"), (200, "ping-pong 8w (round 3)"), (100, "4x64")):
                     ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
                     print(f"  fp8 attend only, {nm:26s} round {rnd_i}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
             for k, nm in ((301, "product, no exp"), (302, "product, no LDS-DMA"), (308, "product, no softmax steps"), (101, "4x64 no exp"), (108, "4x64 no softmax steps")):

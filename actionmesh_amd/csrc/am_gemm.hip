@@ -198,7 +198,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
 
 // Shared tail of the 256x256 kernels: the bf16 tile staged in LDS (row = 512 B, 8-byte unit u of row m at u ^ (m & 15))
 // goes out as row-contiguous 16-byte stores with the residual added on the way.
-__device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const unsigned char* stage, int tid, int m0, int n0) {
+#ifndef AM_GEMM_NT
+#define AM_GEMM_NT 1        // non-temporal residual loads and C stores: both are touched once per GEMM and would only evict the A / W panels the
+#endif                      // XCD's other workgroups are about to re-read from L2 (0 = the A/B build, tools/build_gemm_variants.sh)
+// The residual operand of a full, identity-mapped tile, fetched BEFORE the accumulators are staged through LDS (round 4): 16 loads of
+// 16 bytes per thread in flight at once, their HBM latency under the staging pass and its barrier.  Before, the store loop issued them
+// four at a time between the stores - four exposed round trips of loaded-HBM latency per tile, and a tile of the K = 1024 linears is
+// only ~20 us of main loop.
+struct ResidualPrefetch {
+  u32x4_t rv[16];
+  bool on;
+};
+__device__ __forceinline__ bool residual_prefetchable(const am_gemm_args& p, int tid, int m0, int n0) {
+  return p.residual != nullptr && p.c_G <= 0 && m0 + B2 <= p.M && n0 + (tid & 31) * 8 < p.N && !(p.act & 0x1800);
+}
+__device__ __forceinline__ void residual_prefetch(const am_gemm_args& p, int tid, int m0, int n0, ResidualPrefetch& r) {
+  r.on = residual_prefetchable(p, tid, m0, n0);
+  if (r.on) {
+    const int k16 = tid & 31, r16 = tid >> 5;
+    const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)(n0 + k16 * 8)) * 2u;
+    const int64_t step = (int64_t)16 * p.ldc;
+    const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+      const u32x4_t* q = reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned char*>(rrow + pass * step) + lane_off);
+      r.rv[pass] = AM_GEMM_NT ? __builtin_nontemporal_load(q) : *q;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const unsigned char* stage, int tid, int m0, int n0,
+                                                  const ResidualPrefetch* pre = nullptr) {
   {
     // thread -> 16-byte chunk k16 (8 columns) of rows ml = pass * 16 + (tid >> 5).  (ml & 15) does not depend on the pass,
     // so the chunk sits at a fixed offset of its row and every per-pass LDS address is base + constant.
@@ -231,7 +261,17 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
         const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
         const int64_t step = (int64_t)16 * p.ldc;
         bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
-        if (p.residual && !abl_nores) {
+        if (pre != nullptr && pre->on) {              // residual already in registers (residual_prefetch)
+#pragma unroll
+          for (int pass = 0; pass < 16; ++pass) {
+            u32x4_t sv = fetch(pass);
+            const u32x4_t rv = pre->rv[pass];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
+            u32x4_t* q = reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off);
+            if (AM_GEMM_NT) __builtin_nontemporal_store(sv, q); else *q = sv;
+          }
+        } else if (p.residual && !abl_nores) {
           const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
 #pragma unroll 4
           for (int pass = 0; pass < 16; ++pass) {
@@ -240,8 +280,10 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
           }
         } else {
 #pragma unroll 4
-          for (int pass = 0; pass < 16; ++pass)
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = fetch(pass);
+          for (int pass = 0; pass < 16; ++pass) {
+            u32x4_t* q = reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off);
+            if (AM_GEMM_NT) __builtin_nontemporal_store(fetch(pass), q); else *q = fetch(pass);
+          }
         }
       } else {
 #pragma unroll 2
@@ -740,6 +782,9 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
 
   // ---- epilogue: bf16 tile staged through LDS (row = 512 B = 64 units of 8 B, unit u of row m at u ^ (m & 15)), then the
   // row-contiguous store loop of the v2 kernel ------------------------------------------------------------------------
+  ResidualPrefetch pre;
+  pre.on = false;
+  if constexpr (!HP) residual_prefetch(p, tid, m0, n0, pre);       // 16 loads in flight under the staging pass
   unsigned char* stage = smem;
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi)
@@ -761,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
     }
   __syncthreads();
   if constexpr (HP) store_staged_tile_headpost(p, hp, stage, tid, m0, n0);
-  else store_staged_tile(p, stage, tid, m0, n0);
+  else store_staged_tile(p, stage, tid, m0, n0, &pre);
 }
 #undef PP_QUADRANT
 

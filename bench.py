@@ -139,6 +139,14 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
                 "fallback_workgroups_per_launch": (ops.attention_fallback_count() - f0) / reps}
 
     plain, peaky = sample(1.0), sample(4.0)
+    # Decomposition of `frac`: the firmware's own telemetry (gpu_metrics through amdsmi) sampled at ~20 Hz while the
+    # plain launch runs back to back for ~1.5 s - the delivered gfx clock, the socket power, and how long the PPT (socket power) limiter
+    # was active.  frac = pipe_busy x effective_clock / 2.4 GHz: only the first factor is the kernel's schedule.
+    telemetry = None
+    try:
+        telemetry = clock_telemetry(lambda: attn((Qf * 1.0).to(torch.bfloat16), K, Vt, Sq, Sq, out=out, nchunks=fw), seconds=1.5)
+    except Exception as e:          # no amdsmi / no sysfs in this container: the decomposition is simply absent
+        telemetry = {"error": repr(e)[:200]}
     # the same launch on all-zero operands: nothing toggles, the chip keeps its full clock, and what is left is the instruction
     # stream's own rate (= the MFMA-busy fraction of the counters); the distance from `plain` to it is the power budget
     # (tools/clock_probe.py), not the schedule.  Diagnostic only: never `achieved`.
@@ -160,6 +168,10 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
             "achieved": plain["achieved"], "peak": peak, "unit": "TFLOP/s",
             "frac": plain["frac"], "traffic": traffic, "traffic_source": traffic_src,
             "launch_ms": plain["launch_ms"], "flops_per_launch": flops,
+            "effective_clock_ghz": (telemetry or {}).get("gfxclk_ghz_median"),
+            "pipe_busy": (round(plain["frac"] * 2.4 / telemetry["gfxclk_ghz_median"], 4)
+                          if telemetry and telemetry.get("gfxclk_ghz_median") else None),
+            "clock_telemetry": telemetry,
             "samples": {"plain (scores ~ N(0,1))": plain, "peaky (Q x4: scores ~ N(0,16^2))": peaky,
                         "zero operands (diagnostic: same launch, nothing toggles - the schedule's rate at the full clock)": zeros}}
 
@@ -184,6 +196,63 @@ def reference_full_shape(shape):
         rec["seconds_autocast_bf16"] = round(float(g["fwd_seconds_autocast"]), 1)
     rec["value"] = round(1.0 / float(g["fwd_seconds_fp32"]), 6)
     return rec
+
+
+def clock_telemetry(fn, seconds=1.5):
+    """Run `fn` back to back for `seconds` while a thread samples the firmware's gpu_metrics blob (amdsmi): the median delivered gfx
+    clock over the XCDs, the socket power, and the share of the interval the PPT (socket power), thermal and PROCHOT limiters were
+    active (residency accumulators of gpu_metrics v1.6+; tools/limiter_probe.py is the long form)."""
+    import threading
+    import amdsmi
+    try:
+        amdsmi.amdsmi_init()
+    except Exception:
+        pass
+    h = amdsmi.amdsmi_get_processor_handles()[0]
+    rows, stop = [], [False]
+
+    def loop():
+        while not stop[0]:
+            try:
+                rows.append(amdsmi.amdsmi_get_gpu_metrics_info(h))
+            except Exception:
+                pass
+            time.sleep(0.05)
+    fn(); torch.cuda.synchronize()
+    first = amdsmi.amdsmi_get_gpu_metrics_info(h)
+    th = threading.Thread(target=loop, daemon=True)
+    th.start()
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(4):
+            fn()
+        n += 4
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    last = amdsmi.amdsmi_get_gpu_metrics_info(h)
+    rows = rows[len(rows) // 4:]
+    num = lambda v: isinstance(v, (int, float)) and not isinstance(v, bool)
+    med = lambda v: sorted(v)[len(v) // 2] if v else None
+    clk = [sum(x for x in r["current_gfxclks"] if num(x)) / max(1, sum(1 for x in r["current_gfxclks"] if num(x)))
+           for r in rows if isinstance(r.get("current_gfxclks"), list) and any(num(x) for x in r["current_gfxclks"])]
+    out = {"seconds": seconds, "launches": n, "samples": len(rows),
+           "gfxclk_ghz_median": round(med(clk) / 1e3, 3) if clk else None,
+           "socket_power_w_median": med([r["current_socket_power"] for r in rows if num(r.get("current_socket_power"))])}
+    dacc = (last.get("accumulation_counter") or 0) - (first.get("accumulation_counter") or 0) if num(last.get("accumulation_counter")) and num(first.get("accumulation_counter")) else 0
+    if dacc > 0:
+        for k in ("ppt_residency_acc", "socket_thm_residency_acc", "vr_thm_residency_acc", "hbm_thm_residency_acc", "prochot_residency_acc"):
+            if num(first.get(k)) and num(last.get(k)):
+                out[k.replace("_acc", "_share")] = round((last[k] - first[k]) / dacc, 4)
+    try:
+        cap = amdsmi.amdsmi_get_power_cap_info(h)
+        out["power_cap_w"] = cap.get("power_cap", 0) / 1e6 if num(cap.get("power_cap")) else None
+    except Exception:
+        pass
+    out["limiter"] = ("socket power (PPT)" if out.get("ppt_residency_share", 0) > 0.05 else
+                      "thermal" if max(out.get("socket_thm_residency_share", 0), out.get("hbm_thm_residency_share", 0), out.get("vr_thm_residency_share", 0)) > 0.05
+                      else "none seen")
+    return out
 
 
 def cpu_baseline(hp, sd, step_flops_full, S, T_full, N_full, deep=False, shape=None):

@@ -14,6 +14,9 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ACTIONMESH_AMD_LIB: another build of the same library (kernel A/B variants, tools/build_variants.sh); never a fallback
 LIB_PATH = os.environ.get("ACTIONMESH_AMD_LIB") or os.path.join(_HERE, "libactionmesh_amd.so")
+# The float16 build of the same sources (csrc/Makefile: -DAM_F16): same symbols, the 16-bit storage / MFMA element type is IEEE half.
+# The reference CLI's `--dtype float16` (inference/video_to_animated_mesh.py:153,222).  Loaded on first use, never a fallback.
+LIB_PATH_F16 = os.environ.get("ACTIONMESH_AMD_LIB_F16") or os.path.join(_HERE, "libactionmesh_amd_f16.so")
 ABI_VERSION = 1
 
 
@@ -132,31 +135,44 @@ SYMBOLS = {
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
 }
 
-_lib: Optional[C.CDLL] = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
-    """Load (once) and return the shared library; fail loudly if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def lib(kind: str = "bf16") -> C.CDLL:
+    """Load (once) and return the shared library of the given 16-bit type ("bf16": the product default; "f16": the float16 build);
+    fail loudly if it is absent."""
+    if kind in _libs:
+        return _libs[kind]
+    if kind not in ("bf16", "f16"):
+        raise ValueError(f"actionmesh_amd._lib.lib: kind must be 'bf16' or 'f16', got {kind!r}")
+    path = LIB_PATH if kind == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C actionmesh_amd/csrc`.  actionmesh_amd has no CPU fallback."
         )
-    l = C.CDLL(LIB_PATH)
+    l = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(l, name)   # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     if l.am_abi_version() != ABI_VERSION:
         raise HipLibraryMissing(f"ABI mismatch: library {l.am_abi_version()} != binding {ABI_VERSION}; rebuild")
-    _lib = l
+    _libs[kind] = l
     return l
 
 
-def check(status: int, what: str = "") -> None:
+def kind_of(dtype) -> str:
+    """'bf16' / 'f16' for torch.bfloat16 / torch.float16 (or their names); anything else is an error - there is no fp32 library."""
+    name = str(dtype).replace("torch.", "")
+    if name in ("bfloat16", "bf16"):
+        return "bf16"
+    if name in ("float16", "half", "f16", "fp16"):
+        return "f16"
+    raise ValueError(f"actionmesh_amd: the 16-bit type must be bfloat16 or float16, got {dtype!r}")
+
+
+def check(status: int, what: str = "", l: Optional[C.CDLL] = None) -> None:
     if status != 0:
-        msg = lib().am_last_error().decode(errors="replace")
+        msg = (l if l is not None else lib()).am_last_error().decode(errors="replace")
         raise RuntimeError(f"libactionmesh_amd {what} failed (status {status}): {msg}")

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0], 0, 0, 0);
+        s[0] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0]);
         kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * 256 + k_off[ks]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1], 0, 0, 0);
+        s[1] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1]);
     }
     // V^T fragments of the first two 16-key steps: in flight under the softmax
     bf16x8_t vf[8];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
+        o[d] = AM_MFMA_32x32x16(vf[kk * 4 + d], pf[kk], o[d]);
         vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
     for (int kk = 2; kk < 4; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(kk - 2) * 4 + d], pf[kk], o[d], 0, 0, 0);
+        o[d] = AM_MFMA_32x32x16(vf[(kk - 2) * 4 + d], pf[kk], o[d]);
   };
 
   auto super_tile = [&](int buf, bool more) __attribute__((always_inline)) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_balanced_kernel(am_attn_args 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0], 0, 0, 0);
+        s[0] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0]);
         kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * 256 + k_off[ks]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_balanced_kernel(am_attn_args 
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1], 0, 0, 0);
+        s[1] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1]);
     }
     // ---- softmax, first half: row max, rescale, exp of key block 0 ------------------------------
     asm volatile("s_nop 15" : "+v"(s[0]), "+v"(s[1]));     // MFMA result -> inline-asm VALU read hazard
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_balanced_kernel(am_attn_args 
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kk * 4 + d], pf[kk], o[d], 0, 0, 0);
+        o[d] = AM_MFMA_32x32x16(vf[kk * 4 + d], pf[kk], o[d]);
         vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_balanced_kernel(am_attn_args 
     for (int kk = 2; kk < 4; ++kk)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(kk - 2) * 4 + d], pf[kk], o[d], 0, 0, 0);
+        o[d] = AM_MFMA_32x32x16(vf[(kk - 2) * 4 + d], pf[kk], o[d]);
   };
 
   dma_k(0);

@@ -904,7 +904,11 @@ int am_attention64_main(const am_attn_args* a, int tiles_per_chunk, int nblk_mai
 #endif
   // defer > 0: the lazy kernel (+ exact fallback); defer == 0: the exact kernel with an immediate re-base;
   // a->defer_log2 == 28: the exact kernel with the deferred re-base on its own (A/B, tests)
+#ifdef AM_F16
+  const bool exact = true;                 // float16 build: P in IEEE half cannot carry the lazy re-base's 2^+-60 lags - running row max only
+#else
   const bool exact = a->defer_log2 == 28;
+#endif
   if (a->state_mode == 1)
     return defer == 0 ? launch64<0, 0, 1>(a, tiles_per_chunk, nblk_main, stream)
            : exact    ? launch64<8, 0, 1>(a, tiles_per_chunk, nblk_main, stream)

@@ -7,8 +7,24 @@
 
 #include "../../include/actionmesh_amd.h"
 
-typedef uint16_t bf16_t;  // raw bf16 payload
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
+// The library's 16-bit storage / MFMA element type.  Default: bfloat16 (the reference's default autocast dtype).  The SAME sources built
+// with -DAM_F16 are libactionmesh_amd_f16.so, the reference CLI's `--dtype float16` (inference/video_to_animated_mesh.py:153,222;
+// pipeline.py:671): every "bf16" name below then means IEEE half - storage, conversions (round to nearest even), the rounding points that
+// mirror autocast, and the MFMA element type (v_mfma_f32_32x32x16_f16 / 16x16x32_f16: same shapes, same rate, same register layout).
+// The 4x64 attention runs its EXACT form there (running row max): the lazy re-base of the bf16 build needs bf16's 8-bit exponent for P.
+#ifdef AM_F16
+typedef _Float16 am_h16;
+#define AM_H16_NAME "f16"
+#define AM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define AM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 am_h16;
+#define AM_H16_NAME "bf16"
+#define AM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define AM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef uint16_t bf16_t;  // raw 16-bit payload (bf16; IEEE half in the AM_F16 build)
+typedef __attribute__((ext_vector_type(8))) am_h16 bf16x8_t;   // MFMA A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;  // 16-byte vector load/store unit
@@ -37,7 +53,11 @@ void am_set_error(const char* fmt, ...);
     if (s__ != AM_OK) return s__; \
   } while (0)
 
-// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------
+// ---- 16-bit <-> f32 (round-to-nearest-even, NaN preserved) -------------------
+#ifdef AM_F16
+__host__ __device__ inline float bf2f(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__host__ __device__ inline bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+#else
 __host__ __device__ inline float bf2f(bf16_t b) {
   union { uint32_t u; float f; } c;
   c.u = (uint32_t)b << 16;
@@ -51,11 +71,12 @@ __host__ __device__ inline bf16_t f2bf(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-// Device-side conversions use the gfx950 hardware converter (v_cvt_pk_bf16_f32, RNE).
+#endif
+// Device-side conversions use the gfx950 hardware converters (v_cvt_pk_bf16_f32 / v_cvt_f16_f32, RNE).
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// round an fp32 value to bf16 precision and back (the "autocast result" rounding)
-__device__ inline float rbf(float f) { return (float)(__bf16)f; }
+typedef __attribute__((ext_vector_type(2))) am_h16 bf16x2_t;
+// round an fp32 value to the 16-bit type and back (the "autocast result" rounding)
+__device__ inline float rbf(float f) { return (float)(am_h16)f; }
 __device__ inline uint32_t pack_bf2(float lo, float hi) {
   const f32x2_t f = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = AM_MFMA_32x32x16(bfr[j], af[i], acc[i][j]);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
   }
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = AM_MFMA_32x32x16(bfr[j], af[i], acc[i][j]);
     }
     dma_drain_barrier();             // next tile landed; everyone is done with `buf`
   }
@@ -732,8 +732,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-          acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                              \
-              wf[(NH) * 2 + j][ks], af[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);                         \
+          acc[(MH) * 4 + i][(NH) * 2 + j] = AM_MFMA_16x16x32(                                                     \
+              wf[(NH) * 2 + j][ks], af[i][ks], acc[(MH) * 4 + i][(NH) * 2 + j]);                                  \
     __builtin_amdgcn_s_setprio(0);                                                                                \
   } while (0)
 

@@ -86,8 +86,12 @@ class HipEngine:
     def __init__(self, hp: Dict, state_dict: Dict[str, torch.Tensor], device: torch.device,
                  max_batch: int, frames_local: int, tokens: int, ctx_tokens: int,
                  world: int = 1, rank: int = 0, attn_defer_log2: int = 8, attn_dtype: str = "bf16",
-                 kv_factory=None, use_graph: bool = False):
-        self.lib = L.lib()
+                 kv_factory=None, use_graph: bool = False, dtype="bfloat16"):
+        # the 16-bit storage / MFMA element type: bfloat16 (default) or float16 - the same sources built twice (_lib.lib(kind))
+        self.kind = L.kind_of(dtype)
+        self.h16 = torch.float16 if self.kind == "f16" else torch.bfloat16
+        self.lib = L.lib(self.kind)
+        self._check = lambda status, what="": L.check(status, what, self.lib)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HipEngine needs a ROCm device (torch device type 'cuda'); there is no CPU path")
@@ -112,10 +116,10 @@ class HipEngine:
         cfg.attn_fp8 = {"bf16": 0, "fp8": 1, "fp8_fast": 2}[attn_dtype]
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_create(C.byref(cfg), C.byref(self.handle)), "am_create")
+            self._check(self.lib.am_create(C.byref(cfg), C.byref(self.handle)), "am_create")
             for name, t in state_dict.items():
                 t = t.detach().to("cpu", torch.float32).contiguous()
-                L.check(self.lib.am_load_weight(self.handle, name.encode(), t.data_ptr(), t.numel()),
+                self._check(self.lib.am_load_weight(self.handle, name.encode(), t.data_ptr(), t.numel()),
                         f"am_load_weight({name})")
             missing = self.lib.am_weights_missing(self.handle)
             if missing:
@@ -127,7 +131,7 @@ class HipEngine:
             self._gx = self._gv = self._gstream = None
             if world > 1:
                 n = C.c_size_t()
-                L.check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
+                self._check(self.lib.am_kv_chunk_elems(self.handle, C.byref(n)), "am_kv_chunk_elems")
                 # one buffer [rank][K chunk | V^T chunk]: a single in-place all-gather per layer moves both operands.  An fp8 handle
                 # exchanges the QUANTISED shards (am_bind_kv8_buffers): one byte per element, half the traffic.
                 esz = 1 if attn_dtype.startswith("fp8") else 2
@@ -135,13 +139,13 @@ class HipEngine:
                     self.exchange = kv_factory(2 * n.value * esz)
                     base = self.exchange.kv_ptr()
                 else:
-                    kv = torch.zeros((world, 2 * n.value), dtype=torch.uint8 if esz == 1 else torch.bfloat16, device=self.device)
+                    kv = torch.zeros((world, 2 * n.value), dtype=torch.uint8 if esz == 1 else self.h16, device=self.device)
                     base = kv.data_ptr()
                     self._kv = (kv,)
                 if esz == 1:
-                    L.check(self.lib.am_bind_kv8_buffers(self.handle, base, base + n.value, 2 * n.value), "am_bind_kv8_buffers")
+                    self._check(self.lib.am_bind_kv8_buffers(self.handle, base, base + n.value, 2 * n.value), "am_bind_kv8_buffers")
                 else:
-                    L.check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
+                    self._check(self.lib.am_bind_kv_buffers(self.handle, base, base + n.value * 2, 2 * n.value), "am_bind_kv_buffers")
         self._shape = None
 
     def close(self, collective: bool = True):
@@ -182,11 +186,11 @@ class HipEngine:
         cos = cos.contiguous(); sin = sin.contiguous()
         assert cos.shape == (B * T, HEAD_DIM // 2) and not cos.is_cuda
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_set_context(self.handle, ctx_local.data_ptr(), B, T, S,
+            self._check(self.lib.am_set_context(self.handle, ctx_local.data_ptr(), B, T, S,
                                             cos.data_ptr(), sin.data_ptr(), self._stream()), "am_set_context")
             if (ctx_zero is not None and any(ctx_zero)) or shared_prefix:
                 z = (C.c_uint8 * B)(*[1 if (ctx_zero is not None and ctx_zero[b]) else 0 for b in range(B)])
-                L.check(self.lib.am_set_branch_hints(self.handle, z, 1 if shared_prefix else 0), "am_set_branch_hints")
+                self._check(self.lib.am_set_branch_hints(self.handle, z, 1 if shared_prefix else 0), "am_set_branch_hints")
         self._ctx_keepalive = ctx_local
 
     def begin(self, x_local: torch.Tensor, t_bt_local: List[float]) -> None:
@@ -196,27 +200,27 @@ class HipEngine:
         self._shape = (B, T, N, D)
         self._x_keepalive = x_local
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_forward_begin(self.handle, x_local.data_ptr(), t, B, T, N, self._stream()),
+            self._check(self.lib.am_forward_begin(self.handle, x_local.data_ptr(), t, B, T, N, self._stream()),
                     "am_forward_begin")
 
     def layer_pre(self, layer: int) -> None:
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_layer_pre_attn(self.handle, layer, self._stream()), "am_layer_pre_attn")
+            self._check(self.lib.am_layer_pre_attn(self.handle, layer, self._stream()), "am_layer_pre_attn")
 
     def layer_attn_local(self, layer: int) -> None:
         """Optional overlap step: attention against the local K/V shard while the all-gather is in flight."""
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_layer_attn_local(self.handle, layer, self._stream()), "am_layer_attn_local")
+            self._check(self.lib.am_layer_attn_local(self.handle, layer, self._stream()), "am_layer_attn_local")
 
     def layer_post(self, layer: int) -> None:
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_layer_post_attn(self.handle, layer, self._stream()), "am_layer_post_attn")
+            self._check(self.lib.am_layer_post_attn(self.handle, layer, self._stream()), "am_layer_post_attn")
 
     def end(self) -> torch.Tensor:
         B, T, N, D = self._shape
-        v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+        v = torch.empty((B, T, N, D), dtype=self.h16, device=self.device)
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_forward_end(self.handle, v.data_ptr(), self._stream()), "am_forward_end")
+            self._check(self.lib.am_forward_end(self.handle, v.data_ptr(), self._stream()), "am_forward_end")
         return v
 
     def forward(self, x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
@@ -230,7 +234,7 @@ class HipEngine:
             # ordered after the caller's current stream and before whatever the caller enqueues next
             if self._gx is None or self._gx.shape != x_local.shape:
                 self._gx = torch.empty_like(x_local)
-                self._gv = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+                self._gv = torch.empty((B, T, N, D), dtype=self.h16, device=self.device)
                 self._gstream = torch.cuda.Stream(self.device)
             with torch.cuda.device(self.device):
                 cur = torch.cuda.current_stream(self.device)
@@ -238,28 +242,28 @@ class HipEngine:
                 x_local.record_stream(self._gstream)
                 with torch.cuda.stream(self._gstream):
                     self._gx.copy_(x_local)
-                    L.check(self.lib.am_denoise_forward_graph(self.handle, self._gx.data_ptr(), t, B, T, N, self._gv.data_ptr(),
+                    self._check(self.lib.am_denoise_forward_graph(self.handle, self._gx.data_ptr(), t, B, T, N, self._gv.data_ptr(),
                                                               self._gstream.cuda_stream), "am_denoise_forward_graph")
                 cur.wait_stream(self._gstream)
             # the graph writes ONE persistent buffer: hand out a copy, or a caller that keeps several results (split_cfg_batch
             # collects one velocity per guidance branch and concatenates them) would see them all alias the last forward
             return self._gv.clone()
-        v = torch.empty((B, T, N, D), dtype=torch.bfloat16, device=self.device)
+        v = torch.empty((B, T, N, D), dtype=self.h16, device=self.device)
         with torch.cuda.device(self.device):
-            L.check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),
+            self._check(self.lib.am_denoise_forward(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(),
                                                 self._stream()), "am_denoise_forward")
         return v
 
     def attention_counters(self) -> Tuple[int, int]:
         """(fp8, bf16) inflated self-attention launches of this engine so far: the arithmetic type that really ran."""
         c = (C.c_uint64 * 2)()
-        L.check(self.lib.am_attention_counters(self.handle, c), "am_attention_counters")
+        self._check(self.lib.am_attention_counters(self.handle, c), "am_attention_counters")
         return int(c[0]), int(c[1])
 
     def graph_stats(self) -> Tuple[int, int, int, int]:
         """(replays, captures, eager forwards, capture failed) of am_denoise_forward_graph."""
         c = (C.c_uint64 * 4)()
-        L.check(self.lib.am_graph_stats(self.handle, c), "am_graph_stats")
+        self._check(self.lib.am_graph_stats(self.handle, c), "am_graph_stats")
         return tuple(int(v) for v in c)
 
     def step_flops(self, B: int, T_total: int, N: int, S: int) -> float:
@@ -282,8 +286,12 @@ class HipDenoiser(nn.Module):
                  inflated_layers: Optional[Sequence[int]] = None, clear_autocast: bool = True,
                  compile_blocks: bool = False, compile_mode: str = "default",
                  process_group: Optional[dist.ProcessGroup] = None, attn_defer_log2: int = 8,
-                 cfg_parallel: bool = True, attn_dtype: str = "bf16", use_graph: Optional[bool] = None):
+                 cfg_parallel: bool = True, attn_dtype: str = "bf16", use_graph: Optional[bool] = None, dtype=None):
         super().__init__()
+        # 16-bit storage / MFMA type.  None (default): follow the caller's autocast region like the reference module does - the reference
+        # pipeline runs Stage I under torch.autocast("cuda", dtype) (pipeline.py:671) with dtype from the CLI's --dtype {bfloat16,
+        # float16}; bfloat16 outside any autocast region.  "float16" / "bfloat16" (or the torch dtypes) pin it.
+        self.dtype_pinned = None if dtype is None else L.kind_of(dtype)
         # HIP-graph replay of the single-rank forward (None: the ACTIONMESH_AMD_GRAPH environment variable, default off)
         self.use_graph = (os.environ.get("ACTIONMESH_AMD_GRAPH", "0") == "1") if use_graph is None else bool(use_graph)
         self.attn_dtype = attn_dtype        # "fp8": inflated self-attention on the e4m3 MFMA kernel (BASELINE configs[4])
@@ -361,12 +369,24 @@ class HipDenoiser(nn.Module):
                 dist.new_group([base[r] for r in plan.frame_group_ranks(g)]) for g in range(plan.cfg_groups)]
         return self._frame_groups[plan.cfg_groups][plan.cfg_rank]
 
+    def compute_kind(self) -> str:
+        """'bf16' or 'f16': the pinned dtype, else the autocast dtype of the calling region (float16 only when the caller asked for it)."""
+        if self.dtype_pinned is not None:
+            return self.dtype_pinned
+        try:
+            if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
+                return "f16"
+        except Exception:
+            pass
+        return "bf16"
+
     def _ensure_engine(self, B: int, T_local: int, N: int, S: int, plan: FrameShardPlan) -> HipEngine:
         if self._host_sd is None:
             raise RuntimeError("HipDenoiser: no weights loaded (load_state_dict / from_pretrained first)")
         e = self._engine
+        kind = self.compute_kind()
         if e is not None and e.device == self.device and e.fits(B, T_local, N, S) and e.world == plan.frame_world \
-                and e.rank == plan.frame_rank:
+                and e.rank == plan.frame_rank and e.kind == kind:
             return e
         if e is not None:
             e.close()
@@ -377,7 +397,7 @@ class HipDenoiser(nn.Module):
             kv_factory = lambda chunk_bytes: PeerExchange(group, plan, chunk_bytes, self.device)
         self._engine = HipEngine(self.hyper_params(), self._host_sd, self.device, B, T_local, N, S,
                                  world=plan.frame_world, rank=plan.frame_rank, attn_defer_log2=self.attn_defer_log2,
-                                 attn_dtype=self.attn_dtype, kv_factory=kv_factory, use_graph=self.use_graph)
+                                 attn_dtype=self.attn_dtype, kv_factory=kv_factory, use_graph=self.use_graph, dtype=kind)
         self._window = None
         return self._engine
 

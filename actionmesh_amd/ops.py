@@ -26,7 +26,20 @@ def _launch(t: torch.Tensor, fn, what: str, *args) -> None:
     library launches on the current device) and the stream is torch's current stream OF THAT DEVICE, so a tensor on a
     non-current device is neither launched on device 0's stream nor unordered with the work that produced it."""
     with torch.cuda.device(t.device):
-        L.check(fn(*args, _stream(t.device)), what)
+        L.check(fn(*args, _stream(t.device)), what, getattr(fn, "_am_lib", None))
+
+
+H16 = (torch.bfloat16, torch.float16)       # the two 16-bit storage types: each has its own build of the library (_lib.lib(kind))
+
+
+def _fn(t_or_dtype, name: str):
+    """Entry point `name` of the library whose 16-bit type is that of the tensor (or dtype) given: bfloat16 -> libactionmesh_amd.so,
+    float16 -> libactionmesh_amd_f16.so (the same sources built with -DAM_F16)."""
+    dt = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    l = L.lib("f16" if dt == torch.float16 else "bf16")
+    f = getattr(l, name)
+    f._am_lib = l
+    return f
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -36,7 +49,7 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 def _need(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: actionmesh_amd kernels need a device tensor (no CPU path)")
-    if t.dtype != dtype:
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: must be contiguous")
@@ -63,26 +76,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
     a_map / c_map = (G, group_stride, offset) row maps (G=0: identity)."""
-    _need(a, torch.bfloat16, "a"); _need(w, torch.bfloat16, "w")
+    _need(a, H16, "a"); _need(w, a.dtype, "w")
     K1 = a.shape[1]
     K = w.shape[1]
     N = w.shape[0]
     if M is None:
         M = a.shape[0]
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    _need(out, torch.bfloat16, "out")
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    _need(out, a.dtype, "out")
     g = L.AmGemmArgs()
     g.A1 = a.data_ptr(); g.lda1 = a.stride(0); g.K1 = K1
     g.A2 = _p(a2); g.lda2 = a2.stride(0) if a2 is not None else 0
     if a2 is not None:
-        _need(a2, torch.bfloat16, "a2")
+        _need(a2, a.dtype, "a2")
         assert K1 + a2.shape[1] == K
     else:
         assert K1 == K
     g.W = w.data_ptr(); g.ldw = w.stride(0)
     g.bias = _p(_need(bias, torch.float32, "bias")) if bias is not None else None
-    g.residual = _p(_need(residual, torch.bfloat16, "residual")) if residual is not None else None
+    g.residual = _p(_need(residual, a.dtype, "residual")) if residual is not None else None
     g.C = out.data_ptr(); g.ldc = out.stride(0)
     g.M, g.N, g.K = M, N, K
     # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings);
@@ -90,18 +103,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0xF800)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
-    _launch(a, L.lib().am_gemm_bf16, "am_gemm_bf16", C.byref(g))
+    _launch(a, _fn(a, "am_gemm_bf16"), "am_gemm_bf16", C.byref(g))
     return out
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _need(x, torch.bfloat16, "x"); _need(w, torch.float32, "w"); _need(b, torch.float32, "b")
+    _need(x, H16, "x"); _need(w, torch.float32, "w"); _need(b, torch.float32, "b")
     Cdim = x.shape[-1]
     rows = x.numel() // Cdim
     if out is None:
         out = torch.empty_like(x)
-    _launch(x, L.lib().am_layernorm_bf16, "am_layernorm_bf16", x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
+    _launch(x, _fn(x, "am_layernorm_bf16"), "am_layernorm_bf16", x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
                                       rows, Cdim, eps)
     return out
 
@@ -114,7 +127,7 @@ def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, r
     """Split heads of x (rows, heads*len(kinds)*128), apply qk-RMSNorm (+RoPE), and write the
     attention operand layouts.  Returns (Q, K, Vt) (None for absent kinds):
       Q  (nseq, H, sq_pad, 128), K (nseq, H, sk_pad, 128), Vt (nseq, H, 128, sk_pad)."""
-    _need(x, torch.bfloat16, "x")
+    _need(x, H16, "x")
     rows = x.shape[0]
     nseq = rows // seq_len
     sq_pad, sk_pad = round_up(seq_len, 256), round_up(seq_len, 64)
@@ -130,15 +143,15 @@ def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, r
         a.rope_cos = _need(rope[0], torch.float32, "rope_cos").data_ptr()
         a.rope_sin = _need(rope[1], torch.float32, "rope_sin").data_ptr()
     if 0 in kinds and out_q is None:
-        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=x.dtype, device=dev)
     if 1 in kinds and out_k is None:
-        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=x.dtype, device=dev)
     if 2 in kinds and out_vt is None:
-        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=torch.bfloat16, device=dev)
+        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=x.dtype, device=dev)
     a.out_q = _p(out_q); a.sq_pad = out_q.shape[2] if out_q is not None else 0
     a.out_k = _p(out_k); a.out_vt = _p(out_vt)
     a.sk_pad = out_k.shape[2] if out_k is not None else (out_vt.shape[3] if out_vt is not None else 0)
-    _launch(x, L.lib().am_head_post, "am_head_post", C.byref(a))
+    _launch(x, _fn(x, "am_head_post"), "am_head_post", C.byref(a))
     return out_q, out_k, out_vt
 
 
@@ -150,12 +163,12 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
     """am_gemm_headpost_bf16: (a @ w.T) -> head split / qk-RMSNorm / RoPE / attention layouts in ONE launch; the arguments of `gemm`
     (no bias, no activation) and of `head_post`.  `x` (rows, N) is the linear's output buffer the un-fused pair would use (only the
     tile grid's remainder rows are written to it).  Returns (Q, K, Vt) like head_post."""
-    _need(a, torch.bfloat16, "a"); _need(w, torch.bfloat16, "w")
+    _need(a, H16, "a"); _need(w, a.dtype, "w")
     rows, K = a.shape
     N = w.shape[0]
     assert N == heads * len(kinds) * HEAD_DIM and w.shape[1] == K
     if x is None:
-        x = torch.empty((rows, N), dtype=torch.bfloat16, device=a.device)
+        x = torch.empty((rows, N), dtype=a.dtype, device=a.device)
     nseq = rows // seq_len
     sq_pad, sk_pad = round_up(seq_len, 256), round_up(seq_len, 64)
     dev = a.device
@@ -175,15 +188,15 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
         h.rope_cos = _need(rope[0], torch.float32, "rope_cos").data_ptr()
         h.rope_sin = _need(rope[1], torch.float32, "rope_sin").data_ptr()
     if 0 in kinds and out_q is None:
-        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+        out_q = torch.zeros((nseq, heads, sq_pad, HEAD_DIM), dtype=a.dtype, device=dev)
     if 1 in kinds and out_k is None:
-        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=torch.bfloat16, device=dev)
+        out_k = torch.zeros((nseq, heads, sk_pad, HEAD_DIM), dtype=a.dtype, device=dev)
     if 2 in kinds and out_vt is None:
-        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=torch.bfloat16, device=dev)
+        out_vt = torch.zeros((nseq, heads, HEAD_DIM, sk_pad), dtype=a.dtype, device=dev)
     h.out_q = _p(out_q); h.sq_pad = out_q.shape[2] if out_q is not None else 0
     h.out_k = _p(out_k); h.out_vt = _p(out_vt)
     h.sk_pad = out_k.shape[2] if out_k is not None else (out_vt.shape[3] if out_vt is not None else 0)
-    _launch(a, L.lib().am_gemm_headpost_bf16, "am_gemm_headpost_bf16", C.byref(g), C.byref(h))
+    _launch(a, _fn(a, "am_gemm_headpost_bf16"), "am_gemm_headpost_bf16", C.byref(g), C.byref(h))
     return out_q, out_k, out_vt
 
 
@@ -200,11 +213,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
     Two-pass form (am_attn_args in include/actionmesh_amd.h): `rows` selects the query blocks (1 = the full blocks,
     2 = the rest), `state_mode` 1 saves / 2 resumes the (O, m, l) of the full blocks in `state`
     (nseq * H, sq_pad, STATE_LD) fp32, and the chunks walked are (chunk_first + i) % chunk_total."""
-    _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
+    _need(q, H16, "q"); _need(k, q.dtype, "k"); _need(vt, q.dtype, "vt")
     nseq, H, sq_pad, _ = q.shape
     sk_pad = k.shape[-2]
     if out is None:
-        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=q.dtype, device=q.device)
     a = L.AmAttnArgs()
     a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = nseq, H, sq, sq_pad, sk, sk_pad
@@ -218,7 +231,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, sk: i
         _need(state, torch.float32, "state")
         assert state.numel() >= nseq * H * sq_pad * STATE_LD
         a.state = state.data_ptr()
-    _launch(q, L.lib().am_attention_bf16, "am_attention_bf16", C.byref(a))
+    _launch(q, _fn(q, "am_attention_bf16"), "am_attention_bf16", C.byref(a))
     return out
 
 
@@ -230,11 +243,11 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, s
     """fp8 (e4m3) attention on the bf16 operand layouts of `attention`: quantise (unless `quantized` = (q8, k8, vt8) from an
     earlier call is passed), then QK^T / P.V on the MX-scaled fp8 MFMA.  Returns out (nseq * sq, H * 128) bf16.
     rows / state_mode / state / chunk_first / chunk_total: the two-pass forms, as in `attention`."""
-    _need(q, torch.bfloat16, "q"); _need(k, torch.bfloat16, "k"); _need(vt, torch.bfloat16, "vt")
+    _need(q, H16, "q"); _need(k, q.dtype, "k"); _need(vt, q.dtype, "vt")
     nseq, H, sq_pad, _ = q.shape
     sk_pad = k.shape[-2]
     if out is None:
-        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((nseq * sq, H * HEAD_DIM), dtype=q.dtype, device=q.device)
     a = L.AmAttnArgs()
     a.Q, a.K, a.Vt, a.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     a.nseq, a.heads, a.sq, a.sq_pad, a.sk, a.sk_pad = nseq, H, sq, sq_pad, sk, sk_pad
@@ -252,11 +265,11 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, sq: int, s
         q8 = torch.empty(q.shape, dtype=torch.uint8, device=q.device)
         k8 = torch.empty(k.shape, dtype=torch.uint8, device=q.device)
         vt8 = torch.empty(vt.shape, dtype=torch.uint8, device=q.device)
-        _launch(q, L.lib().am_attention_quantize_fp8, "am_attention_quantize_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(),
+        _launch(q, _fn(q, "am_attention_quantize_fp8"), "am_attention_quantize_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(),
                 vt8.data_ptr())
     else:
         q8, k8, vt8 = quantized
-    _launch(q, L.lib().am_attention_fp8, "am_attention_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr())
+    _launch(q, _fn(q, "am_attention_fp8"), "am_attention_fp8", C.byref(a), q8.data_ptr(), k8.data_ptr(), vt8.data_ptr())
     attention_fp8.last_quantized = (q8, k8, vt8)
     return out
 
@@ -268,10 +281,11 @@ def attention_fallback_count() -> int:
     return int(n.value)
 
 
-def f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+def f32_to_bf16(x: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """fp32 -> the 16-bit type (round to nearest even); `dtype=torch.float16` runs the float16 build of the library."""
     _need(x, torch.float32, "x")
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _launch(x, L.lib().am_f32_to_bf16, "am_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel())
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _launch(x, _fn(dtype, "am_f32_to_bf16"), "am_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel())
     return y
 
 
@@ -313,13 +327,13 @@ def displacement(logits: torch.Tensor, out_dim: int, out: torch.Tensor) -> torch
 def flow_step(v: torch.Tensor, latents: torch.Tensor, scales: Sequence[float], dt: float,
               is_additive: bool, unobserved: Optional[Sequence[bool]]) -> None:
     """In place: latents (T, N, D) fp32 += sign * bf16(dt * cfg(v)); v (n_branches, T, N, D) bf16."""
-    _need(v, torch.bfloat16, "v"); _need(latents, torch.float32, "latents")
+    _need(v, H16, "v"); _need(latents, torch.float32, "latents")
     nb, T, N, D = v.shape
     sc = (C.c_float * max(1, len(scales)))(*[float(s) for s in scales])
     un = None
     if unobserved is not None:
         un = (C.c_uint8 * T)(*[1 if u else 0 for u in unobserved])
-    _launch(v, L.lib().am_flow_step, "am_flow_step", v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
+    _launch(v, _fn(v, "am_flow_step"), "am_flow_step", v.data_ptr(), latents.data_ptr(), nb, sc, float(dt), 1 if is_additive else 0,
                                  un, T, N, D)
 
 

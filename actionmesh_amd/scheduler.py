@@ -152,8 +152,9 @@ class HipSchedulerFlow:
         for i in it:
             t = float(timesteps[i])
             dt = float(distances[i])
-            if self.cuda_autocast_dt:
-                dt = float(torch.tensor(dt, dtype=torch.float32).to(torch.bfloat16))
+            if self.cuda_autocast_dt:          # the 16-bit type the model computes in (bfloat16, or float16 under --dtype float16)
+                h16 = torch.float16 if diffusion_model.compute_kind() == "f16" else torch.bfloat16
+                dt = float(torch.tensor(dt, dtype=torch.float32).to(h16))
             # every launch of the step goes to the denoiser's device and that device's current stream, whichever device is
             # current in the calling thread (the forward and the CFG+Euler kernel must share a stream to be ordered)
             with torch.cuda.device(dev):

@@ -178,6 +178,44 @@ def test_baseline_arch_forward_and_per_step_latents(dev, golden_dir, name, dtype
     assert final < tol_cap(dtype, steps - 1)
 
 
+def test_float16_mode_against_the_reference(dev, golden_dir):
+    """`--dtype float16` of the reference CLI (inference/video_to_animated_mesh.py:153,222): HipDenoiser(dtype="float16") - the float16
+    build of the library, exact (running-max) 4x64 attention - at the headline architecture (21 layers, depth-10 skips) for 30 sampler steps,
+    against the fp32 run of the reference's own modules; the tolerance is RELATIVE to the reference's own float16 curve (the same modules
+    under torch.autocast("cpu", dtype=float16), oracle/make_golden_f16.py -> tests/golden/arch_headline_f16.npz): 1.25 x that curve + 3e-4
+    per step.  IEEE half carries 10 mantissa bits, so both curves sit ~8x below their bf16 twins."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    name = "arch_headline"
+    path = os.path.join(golden_dir, f"{name}_f16.npz")
+    if not os.path.exists(path):
+        pytest.skip("arch_headline_f16.npz not generated (oracle/make_golden_f16.py)")
+    g16 = np.load(path)
+    g, cfg, sd, model, inp, steps = _case(name, golden_dir, dev, dtype="float16")
+    assert np.allclose(g16["inputs_checksum"], g["inputs_checksum"], rtol=1e-12)
+    stride = int(g["token_stride"])
+    v = _forward(model, inp, float(g["fwd_t"]), dev)
+    assert model._engine.kind == "f16"
+    r_fwd, ref_fwd = rel(v, torch.from_numpy(g["fwd_velocity_fp32"])), float(g16["fwd_ref_autocast_f16_vs_fp32"])
+    print(f"{name} [float16]: forward rel-L2 vs reference fp32 {r_fwd:.3e} (reference autocast(float16) vs its fp32: {ref_fwd:.3e})")
+    assert torch.isfinite(v).all() and r_fwd < 1.25 * ref_fwd + 3e-4
+    sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    ref = torch.from_numpy(g["loop_latents_sub_fp32"])
+    ref_curve = g16["ref_autocast_f16_curve"]
+    init = inp["init_latent"].clone().to(dev)
+    curve = []
+    for i, (lat, _t) in enumerate(sched._flow_sample(model, cfgd, init, inp["context"].to(dev), device=dev,
+                                                     mask=inp["mask"].to(dev), framestep=inp["framestep"].to(dev))):
+        sub = lat[:, :, ::stride].cpu()
+        curve.append(rel(sub, ref[i]))
+        assert torch.equal(sub[0, 0], inp["init_latent"][0, 0, ::stride])
+    print(f"{name} [float16]: per-step latents rel-L2 vs reference fp32: " + " ".join(f"{c:.2e}" for c in curve))
+    print(f"{name}: reference autocast(float16) vs its fp32:          " + " ".join(f"{c:.2e}" for c in ref_curve))
+    _record(name + "_float16", dict(forward=r_fwd, ref_forward=ref_fwd, curve=curve, ref_autocast_f16_curve=[float(c) for c in ref_curve]))
+    for i, c in enumerate(curve):
+        assert c < 1.25 * float(ref_curve[i]) + 3e-4, (i, c, float(ref_curve[i]))
+
+
 @pytest.mark.parametrize("name", ["arch_headline_peaky", "arch_headline_spiky"])
 def test_peaky_attention_inside_the_full_model(dev, golden_dir, name):
     """Trained qk-norm gains make attention peaky; the lazy re-base and the exact fallback of the product attention kernel must

@@ -15,12 +15,14 @@ from actionmesh_amd import _lib, denoiser, scheduler
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_loads_and_exports_every_declared_symbol():
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_library_loads_and_exports_every_declared_symbol(kind):
+    """Both builds of the sources: libactionmesh_amd.so (bfloat16) and libactionmesh_amd_f16.so (-DAM_F16: `--dtype float16`)."""
     header = open(os.path.join(ROOT, "include", "actionmesh_amd.h")).read()
     declared = set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", header))
     declared -= {"am_status"}
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    lib = _lib.lib()            # raises if the .so is missing / lacks a symbol / ABI mismatch
+    lib = _lib.lib(kind)        # raises if the .so is missing / lacks a symbol / ABI mismatch
     for name in declared:
         assert hasattr(lib, name)
     assert lib.am_abi_version() == _lib.ABI_VERSION
@@ -202,7 +204,8 @@ def test_attn64_register_audit(tmp_path):
 
 
 
-def test_no_swapped_packed_f32_in_the_built_library(tmp_path):
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_no_swapped_packed_f32_in_the_built_library(tmp_path, kind):
     """Round 3 root cause of the same-device divergence: on MI355X `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[0,0]`
     (low result = src0.lo x src1.HI) returns a wrong low half in lanes 48-63 while another process runs bf16 GEMMs on the device
     (tools/repro/pk_mul_cross_process.hip).  hipcc's SLP vectoriser emitted it for head_post's RoPE rotation; the row-wise kernels are
@@ -212,7 +215,8 @@ def test_no_swapped_packed_f32_in_the_built_library(tmp_path):
     import re
     import shutil
     import subprocess
-    from actionmesh_amd import LIB_PATH
+    from actionmesh_amd import _lib as L_
+    LIB_PATH = L_.LIB_PATH if kind == "bf16" else L_.LIB_PATH_F16
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not (os.path.exists(LIB_PATH) and os.path.exists(objdump)):
         pytest.skip("library or llvm-objdump missing")

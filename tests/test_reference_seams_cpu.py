@@ -68,7 +68,7 @@ class StandInEngine:
                                   num_attention_heads=hp["num_attention_heads"], width=hp["width"],
                                   mlp_ratio=hp["mlp_ratio"], cross_attention_dim=hp["cross_attention_dim"],
                                   inflated_layers=tuple(hp["inflated_layers"]))
-        self.device, self.world, self.rank = torch.device("cpu"), 1, 0
+        self.device, self.world, self.rank, self.kind = torch.device("cpu"), 1, 0, "bf16"
         self.binds = 0
 
     def fits(self, *a):

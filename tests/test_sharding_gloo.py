@@ -218,8 +218,9 @@ class FakeHipEngine(OracleEngine):
     """Same constructor / methods as actionmesh_amd.denoiser.HipEngine, computing with the oracle."""
 
     def __init__(self, hp, state_dict, device, max_batch, frames_local, tokens, ctx_tokens,
-                 world=1, rank=0, attn_defer_log2=8, attn_dtype="bf16", kv_factory=None, use_graph=False):
+                 world=1, rank=0, attn_defer_log2=8, attn_dtype="bf16", kv_factory=None, use_graph=False, dtype="bfloat16"):
         self.device = torch.device(device)
+        self.kind = "f16" if "16" in str(dtype) and "bf" not in str(dtype) else "bf16"
         self.world, self.rank = world, rank
         self.bounds = (max_batch, frames_local, tokens, ctx_tokens)
         self._cfg = O.OracleConfig(in_channels=hp["in_channels"], num_layers=hp["num_layers"],

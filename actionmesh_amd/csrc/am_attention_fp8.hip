@@ -1175,19 +1175,25 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     for (int e = 0; e < 2; ++e) k_off[s][e] = l31 * HD8 + (((4 * s + 2 * hi + e) ^ ksw) << 4);
 #pragma unroll
   for (int e = 0; e < 2; ++e) v_off[e] = 8192 + l31 * 64 + (((2 * hi + e) ^ vsw) << 4);
+  bool in_loop = false;
+  i32x8_t stale = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+  X_PIN(stale);
   auto k_frag = [&](int tt, int kb, int s2) __attribute__((always_inline)) {
+    if ((ABL & 32) && in_loop) return stale;
     const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + kb * 32 * HD8;
     const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + k_off[s2][0]);
     const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + k_off[s2][1]);
     return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
   auto v_frag = [&](int tt, int cb) __attribute__((always_inline)) {
+    if ((ABL & 32) && in_loop) return stale;
     const unsigned char* slot = smem + (tt & (NSTAGE - 1)) * STAGE_BYTES + cb * 32 * 64;
     const u32x4_t a = *reinterpret_cast<const u32x4_t*>(slot + v_off[0]);
     const u32x4_t b = *reinterpret_cast<const u32x4_t*>(slot + v_off[1]);
     return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   };
   auto ones_frag = [&]() __attribute__((always_inline)) {
+    if ((ABL & 32) && in_loop) return stale;
     const unsigned char* q = smem + P_LDS_ONES + lane * 32;
     const u32x4_t a = *reinterpret_cast<const u32x4_t*>(q);
     const u32x4_t b = *reinterpret_cast<const u32x4_t*>(q + 16);
@@ -1239,12 +1245,13 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
 
   auto iteration = [&](const int t, f32x16_t& sbc, f32x16_t& sbn, i32x8_t& pc, i32x8_t& pn) __attribute__((always_inline)) {
     stamp(t, 0);
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");      // tile t+1 has landed everywhere (tiles t+2, t+3 in flight)
+    if (!(ABL & 4)) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");      // tile t+1 has landed everywhere (tiles t+2, t+3 in flight)
     stamp(t, 1);
     const bool first = MODE != 2 && t == 0;
     const bool last_of_chunk = tic == p.tiles_per_chunk - 1;
     tic = last_of_chunk ? 0 : tic + 1;
     XRowMax rm;
+    rm.mx = 0.f;
 #define STEPS_A(G) do { if (!(ABL & 8)) Half::template run<HN * (G) / 4, HN * ((G) + 1) / 4>(sa, pn, 0); } while (0)      /* share G of 4 of the kb = 0 half */
 #define STEPS_B(G) do { if (!(ABL & 8)) Half::template run<HN * (G) / 3, HN * ((G) + 1) / 3>(sbc, pn, 1); } while (0)     /* share G of 3 of the kb = 1 half */
     if (last_of_chunk && tail_valid < KT) {                  // rare, wave-uniform: keys past the chunk's end
@@ -1270,12 +1277,12 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     p_pv(o[2], fc, pc, one);                      // j2
     fc = k_frag(t + 1, 1, 0);                     // for j5
 #pragma unroll
-    for (int n = 0; n < 10; ++n) rm.step(n, sa, sbc, hi);
+    for (int n = 0; n < 10; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
     X_FENCE();
     p_pv(o[3], fa, pc, one);                      // j3
     fa = k_frag(t + 1, 0, 0);                     // for j6
 #pragma unroll
-    for (int n = 10; n < 20; ++n) rm.step(n, sa, sbc, hi);
+    for (int n = 10; n < 20; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
     X_FENCE();
     stamp(t, 2);
     bool flag = false;
@@ -1333,11 +1340,13 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
   };
 
   int t = 0;
+  in_loop = true;
   for (; t + 1 < all_tiles; t += 2) {
     iteration(t, sb[0], sb[1], pf[0], pf[1]);
     iteration(t + 1, sb[1], sb[0], pf[1], pf[0]);
   }
   if (t < all_tiles) iteration(t, sb[0], sb[1], pf[0], pf[1]);
+  in_loop = false;
   const bool odd = (all_tiles & 1) != 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sa), "+v"(sb[0]), "+v"(sb[1]));
@@ -1440,6 +1449,9 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
   AM_ONCE_PER_DEVICE({ X64_ATTR(0, 0); X64_ATTR(1, 0); X64_ATTR(2, 0); X64_ATTR(8, 0); X64_ATTR(0, 1); X64_ATTR(0, 2); });
 #undef X64_ATTR
 #define P_ATTR(...) AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8p_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES))
+#ifdef AM_ATTN_ABLATIONS
+  AM_ONCE_PER_DEVICE({ P_ATTR(12, 0, 0); P_ATTR(24, 0, 0); P_ATTR(40, 0, 0); P_ATTR(10, 0, 0); P_ATTR(62, 0, 0); P_ATTR(4, 0, 0); P_ATTR(16, 0, 0); P_ATTR(32, 0, 0); });
+#endif
   AM_ONCE_PER_DEVICE({ P_ATTR(0, 0, 0); P_ATTR(1, 0, 0); P_ATTR(2, 0, 0); P_ATTR(8, 0, 0); P_ATTR(0, 1, 0); P_ATTR(0, 2, 0); P_ATTR(0, 0, 1); P_ATTR(0, 1, 1); P_ATTR(0, 2, 1); });
 #undef P_ATTR
   AM_ONCE_PER_DEVICE({ F8_ATTR(0, 0); F8_ATTR(1, 0); F8_ATTR(2, 0); F8_ATTR(4, 0); F8_ATTR(8, 0); F8_ATTR(16, 0); F8_ATTR(17, 0); F8_ATTR(6, 0);
@@ -1490,6 +1502,16 @@ extern "C" int am_attention_fp8(const am_attn_args* a, const uint8_t* q8, const 
       case 1: P_LAUNCH(1, 0, 0, grid); break;
       case 2: P_LAUNCH(2, 0, 0, grid); break;
       case 8: P_LAUNCH(8, 0, 0, grid); break;
+#ifdef AM_ATTN_ABLATIONS
+      case 12: P_LAUNCH(12, 0, 0, grid); break;
+      case 24: P_LAUNCH(24, 0, 0, grid); break;
+      case 40: P_LAUNCH(40, 0, 0, grid); break;
+      case 10: P_LAUNCH(10, 0, 0, grid); break;
+      case 62: P_LAUNCH(62, 0, 0, grid); break;
+      case 4: P_LAUNCH(4, 0, 0, grid); break;
+      case 16: P_LAUNCH(16, 0, 0, grid); break;
+      case 32: P_LAUNCH(32, 0, 0, grid); break;
+#endif
       default: AM_FAIL(AM_ERR_INVALID, "am_attention_fp8: unknown ablation code %d", a->defer_log2);
     }
   } else

@@ -74,8 +74,17 @@ def main():
             for k, nm in ((301, "product, no exp"), (302, "product, no LDS-DMA"), (308, "product, no softmax steps"), (101, "4x64 no exp"), (108, "4x64 no softmax steps")):
                 ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
                 print(f"  fp8 ablation {nm:24s}: {ms:8.3f} ms")
-        if a.ablate_fp8:
+        if a.ablate_fp8:            # round 4: where the product (free-running) kernel's tile time goes (needs tools/build_fp8_prof.sh + ACTIONMESH_AMD_LIB)
+            ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out)
             qz = ops.attention_fp8.last_quantized
+            for k, nm in ((300, "full"), (308, "no softmax steps"), (304, "no barrier / vmcnt wait"), (316, "no row max"), (332, "no fragment reads"),
+                          (312, "no steps, no barrier"), (324, "no steps, no row max"), (340, "no steps, no fragment reads"), (310, "no steps, no LDS-DMA"),
+                          (362, "MFMAs only (no steps / barrier / row max / reads / DMA)")):
+                try:
+                    ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
+                    print(f"  fp8 product ablation {nm:56s}: {ms:8.3f} ms")
+                except RuntimeError as e:
+                    print(f"  fp8 product ablation {nm}: unavailable in this build ({str(e)[:60]})")
             for k, nm in {1: "no exp", 16: "no row max", 17: "no exp, no row max", 2: "no LDS-DMA", 4: "no fragment reads", 6: "no DMA, no reads", 8: "no MFMAs", 32: "no s_setprio (full kernel)", 64: "s_setprio 1 on the softmax interval (full)", 40: "no setprio, no MFMAs"}.items():
                 ms = timeit(lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=k), a.reps)
                 print(f"  fp8 ablation {nm:24s}: {ms:8.3f} ms")

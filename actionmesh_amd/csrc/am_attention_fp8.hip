@@ -1263,6 +1263,63 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
         if (32 + (r & 3) + 8 * (r >> 2) >= tv) sbc[r] = -INFINITY;
       }
     }
+    bool flag = false;
+    float alpha = 1.f;
+    if constexpr (FAST != 0) {
+      // fp8_fast: the conversions are SPECULATIVE - a saturating v_cvt_pk_u8_f32 cannot trap, and nothing reads P(t) before the next
+      // tile - so the row max is no longer in front of them: its dependent chain (20 steps, the half-lane swap, the ballot) runs
+      // BESIDE the conversions of the keys-0-31 half and is only checked before the MFMA that overwrites those scores (j6).  The
+      // rare path (a row max above the deferred threshold, or the first tile) shifts the scores and the splat, repeats the 16
+      // conversions of the first half, and shifts the keys-32-63 scores of tile t+1 that j5 has already started on the old splat.
+      X_FENCE();
+      p_pv(o[0], fa, pc, one);                      // j0
+      if (!(ABL & 2)) stage_k();
+      fa = v_frag(t + 7, 3);
+      X_FENCE();
+      p_pv(o[1], fb, pc, one);                      // j1
+      if (!(ABL & 2)) stage_v();
+      fb = ones_frag();
+      X_FENCE();
+      p_pv(o[2], fc, pc, one);                      // j2
+      fc = k_frag(t + 1, 1, 0);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
+      STEPS_A(0);
+      X_FENCE();
+      p_pv(o[3], fa, pc, one);                      // j3
+      fa = k_frag(t + 1, 0, 0);
+#pragma unroll
+      for (int n = 5; n < 10; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
+      STEPS_A(1);
+      X_FENCE();
+      p_pv(lacc, fb, pc, one);                      // j4
+      fb = k_frag(t + 1, 1, 1);
+#pragma unroll
+      for (int n = 10; n < 15; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
+      STEPS_A(2);
+      X_FENCE();
+      qk_first(sbn, fc);                            // j5
+      fc = k_frag(t + 1, 0, 1);
+#pragma unroll
+      for (int n = 15; n < 20; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
+      STEPS_A(3);
+      X_FENCE();
+      stamp(t, 2);
+      if (first || __builtin_amdgcn_ballot_w64(rm.mx > THR) != 0) {     // rare: re-base, then redo the first half
+        const float du = first ? rm.mx - TOP : fmaxf(rm.mx - TOP, 0.f);
+        const float delta = du * (1.f / SC);
+        alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] -= du; sbc[r] -= du; bs[r] = SC * (P_SHIFT - m_run) + OFF; }
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sbn));       // j5 has landed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sbn[r] -= du;
+        X_PIN(sbn);
+        flag = true;
+        Half::template run<0, HN>(sa, pn, 0);
+      }
+    } else {
     // The four P.V MFMAs need nothing of this tile's softmax: they are issued first, so that they EXECUTE under the two LDS-DMA pieces
     // (~150 cycles of issue stall each) and under the dependent row-max chain - the wave's own stalls are covered by its own MFMAs.
     X_FENCE();
@@ -1285,8 +1342,6 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     for (int n = 10; n < 20; ++n) if (!(ABL & 16)) rm.step(n, sa, sbc, hi);
     X_FENCE();
     stamp(t, 2);
-    bool flag = false;
-    float alpha = 1.f;
     if (first || __builtin_amdgcn_ballot_w64(rm.mx > THR) != 0) {     // rare: re-base
       const float du = first ? rm.mx - TOP : fmaxf(rm.mx - TOP, 0.f);
       const float delta = du * (1.f / SC);
@@ -1306,6 +1361,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
     STEPS_A(1);
     STEPS_A(2);
     STEPS_A(3);                                   // the kb = 0 half of S(t) is consumed
+    }
     X_FENCE();
     qk_first(sa, fa);                             // j6: keys 0-31 of tile t+1, into the registers S(t) has just left
     fa = v_frag(t, 0);                            // for the next tile's j0

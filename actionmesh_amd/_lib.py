@@ -45,6 +45,7 @@ class AmGemmArgs(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("act", C.c_int32),
         ("a_G", C.c_int32), ("a_gs", C.c_int32), ("a_off", C.c_int32),
         ("c_G", C.c_int32), ("c_gs", C.c_int32), ("c_off", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_part", C.c_void_p),
     ]
 
 
@@ -114,6 +115,10 @@ SYMBOLS = {
     "am_step_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),
     "am_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "am_row_stats_bf16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "am_row_stats_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.c_float, _P]),
+    "am_layernorm_stats_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P, _P]),
+    "am_ln_fold_weight": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "am_head_post": (C.c_int, [C.POINTER(AmHeadPostArgs), _P]),
     "am_gemm_headpost_bf16": (C.c_int, [C.POINTER(AmGemmArgs), C.POINTER(AmHeadPostArgs), _P]),
     "am_attention_bf16": (C.c_int, [C.POINTER(AmAttnArgs), _P]),

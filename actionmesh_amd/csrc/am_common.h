@@ -94,6 +94,50 @@ __device__ inline void rope_rotate(float& x0, float& x1, float c, float s) {
   x1 = __builtin_fmaf(a, s, bc);
 }
 
+// ---- canonical LayerNorm row statistics (the folded LayerNorms of am_model.hip) ------------------------------------------------
+// A row's (mean, rstd) must be the same BITS whichever kernel wrote the row - a GEMM's store loop (emit_row_part, am_gemm.hip), the
+// read-back pass behind a GEMM (row_part_kernel), a LayerNorm's own output, or the stand-alone statistics pass - because the exact
+// shortcuts of am_set_branch_hints and the graph replays are tested bit for bit against the full computation.  One definition:
+//   slice   = 256 consecutive columns = 32 groups of 8 values;
+//   level 0 = (mean, M2) of a group: the balanced sum / 8, then M2 by an fma chain over (x - mean);
+//   1 ... 5 = equal-count merges  mean = (a + b) / 2,  M2 = M2a + M2b + (a - b)^2 n / 2  (Chan et al.) up a balanced binary tree of
+//             neighbouring groups (lane xor 1, 2, 4, 8, 16; both partners of a merge compute identical values, so any lane of the
+//             other half is a valid partner - DPP mirrors in the GEMM, shuffles in the row kernels);
+//   slices  -> row: merged left to right by row_stats_merge.
+// Every operation is spelled as the instruction it must become (explicit fmaf; products and sums that feed an fma only through
+// its multiplicand / a named temporary), so that the compiler's contraction choices cannot differ between the kernels.
+__device__ __forceinline__ void row_part8(const float (&x)[8], float& mean, float& m2) {
+  mean = (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * 0.125f;
+  m2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float d = x[e] - mean;
+    m2 = __builtin_fmaf(d, d, m2);
+  }
+}
+__device__ __forceinline__ void row_part_merge_equal(float& mean, float& m2, float om, float oq, float half_n) {
+  const float d = om - mean;
+  const float dd = d * d;
+  const float s = m2 + oq;
+  m2 = __builtin_fmaf(dd, half_n, s);
+  mean = 0.5f * (mean + om);
+}
+__device__ __forceinline__ void row_stats_merge(float& n, float& mean, float& m2, float nj, float mj, float qj) {
+  const float tot = n + nj;
+  const float d = mj - mean;
+  const float w = nj / tot;
+  mean = __builtin_fmaf(d, w, mean);
+  const float dd = d * d;
+  const float k = n * w;
+  const float s = m2 + qj;
+  m2 = __builtin_fmaf(dd, k, s);
+  n = tot;
+}
+__device__ __forceinline__ float row_stats_rstd(float n, float m2, float eps) {
+  const float var = m2 / n;
+  return rsqrtf(var + eps);
+}
+
 // erf-GELU (F.gelu(approximate="none")).  erfc(|x|/sqrt2) by Abramowitz-Stegun 7.1.26 on the hardware
 // rcp / exp2: |error| <= 3.3e-7 absolute, <= 1.7e-4 relative for |gelu| > 1e-3 - an order of magnitude
 // below the bf16 rounding applied to the result - at ~14 instructions instead of ~50 for libm erff

@@ -160,9 +160,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
   const int c8 = (tid & 15) * 8;
   const int gn = n0 + c8;
   if (gn < p.N) {
-    float bv[8];
+    float bv[8], cs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[gn + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      bv[e] = p.bias ? p.bias[gn + e] : 0.f;
+      cs[e] = p.ln_stats ? p.ln_colsum[gn + e] : 0.f;
+    }
 #pragma unroll
     for (int pass = 0; pass < BM / 16; ++pass) {
       const int row = pass * 16 + (tid >> 4);
@@ -172,8 +175,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(&Cs[row * CS_LD + c8]);
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(&Cs[row * CS_LD + c8 + 4]);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (p.ln_stats) {                                           // folded LayerNorm: same two FMAs as the 256x256 kernel
+          const f32x2_t st = *reinterpret_cast<const f32x2_t*>(p.ln_stats + 2 * (int64_t)gmr);
+          const float nm = -st[0] * st[1];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);       // nn.Linear result in bf16
+          for (int e = 0; e < 8; ++e) v[e] = rbf(fmaf(v[e], st[1], fmaf(nm, cs[e], bv[e])));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = rbf(v[e] + bv[e]);     // nn.Linear result in bf16
+        }
         if ((p.act & 0xff) == 1) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = rbf(gelu_erf(v[e]));   // F.gelu on bf16 -> bf16
@@ -227,6 +237,32 @@ __device__ __forceinline__ void residual_prefetch(const am_gemm_args& p, int tid
   }
 }
 
+// LayerNorm statistics of the rows this tile writes, for the linear that consumes them (am_gemm_args.ln_part): the store loop's
+// thread holds 8 consecutive bf16 results of one row, a row's 256 columns are 32 lanes - exactly the groups and the tree of the
+// canonical definition in am_common.h.  The tree runs on DPP: quad_perm xor 1, xor 2, row_half_mirror, row_mirror inside the 16-lane
+// row, row_bcast15 into the odd row; lane 31 of each half-wave ends with the slice's (mean, M2).  No sum of squares anywhere:
+// nothing cancels however far a row sits from zero.
+__device__ __forceinline__ void emit_row_part(const u32x4_t& sv, float* part_row, bool writer) {
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { x[2 * e] = bflo(sv[e]); x[2 * e + 1] = bfhi(sv[e]); }
+  float mean, m2;
+  row_part8(x, mean, m2);
+#define AM_CHAN_STEP(CTRL, ROWMASK, HALF_N)                                                                                  \
+  {                                                                                                                          \
+    const float om = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, mean), __builtin_bit_cast(int, mean), CTRL, ROWMASK, 0xf, false)); \
+    const float oq = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m2), __builtin_bit_cast(int, m2), CTRL, ROWMASK, 0xf, false));     \
+    row_part_merge_equal(mean, m2, om, oq, HALF_N);                                                                          \
+  }
+  AM_CHAN_STEP(0xB1, 0xf, 4.f)      // quad_perm [1,0,3,2]
+  AM_CHAN_STEP(0x4E, 0xf, 8.f)      // quad_perm [2,3,0,1]
+  AM_CHAN_STEP(0x141, 0xf, 16.f)    // row_half_mirror
+  AM_CHAN_STEP(0x140, 0xf, 32.f)    // row_mirror
+  AM_CHAN_STEP(0x142, 0xa, 64.f)    // row_bcast15 into rows 1 and 3 (rows 0 and 2 merge with themselves: never written)
+#undef AM_CHAN_STEP
+  if (writer) *reinterpret_cast<f32x2_t*>(part_row) = f32x2_t{mean, m2};
+}
+
 __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const unsigned char* stage, int tid, int m0, int n0,
                                                   const ResidualPrefetch* pre = nullptr) {
   {
@@ -261,6 +297,10 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
         const uint32_t lane_off = ((uint32_t)r16 * (uint32_t)p.ldc + (uint32_t)gn) * 2u;
         const int64_t step = (int64_t)16 * p.ldc;
         bf16_t* crow = p.C + (int64_t)m0 * p.ldc;
+        // ln_part (am_gemm_bf16 passes it down only when N % 256 == 0): slice n0 / 256 of rows m0 + pass * 16 + r16
+        const int nparts = p.N >> 8;
+        float* prow = p.ln_part ? p.ln_part + 2 * ((int64_t)(m0 + r16) * nparts + (n0 >> 8)) : nullptr;
+        const bool pwriter = k16 == 31;
         if (pre != nullptr && pre->on) {              // residual already in registers (residual_prefetch)
 #pragma unroll
           for (int pass = 0; pass < 16; ++pass) {
@@ -270,6 +310,7 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
             for (int e = 0; e < 4; ++e) sv[e] = pack_bf2(bflo(sv[e]) + bflo(rv[e]), bfhi(sv[e]) + bfhi(rv[e]));
             u32x4_t* q = reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off);
             if (AM_GEMM_NT) __builtin_nontemporal_store(sv, q); else *q = sv;
+            if (prow) emit_row_part(sv, prow + (int64_t)pass * 32 * nparts, pwriter);
           }
         } else if (p.residual && !abl_nores) {
           const bf16_t* rrow = p.residual + (int64_t)m0 * p.ldc;
@@ -277,12 +318,15 @@ __device__ __forceinline__ void store_staged_tile(const am_gemm_args& p, const u
           for (int pass = 0; pass < 16; ++pass) {
             const u32x4_t sv = add_res(fetch(pass), reinterpret_cast<const bf16_t*>(reinterpret_cast<const unsigned char*>(rrow + pass * step) + lane_off));
             *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off) = sv;
+            if (prow) emit_row_part(sv, prow + (int64_t)pass * 32 * nparts, pwriter);
           }
         } else {
 #pragma unroll 4
           for (int pass = 0; pass < 16; ++pass) {
             u32x4_t* q = reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(crow + pass * step) + lane_off);
-            if (AM_GEMM_NT) __builtin_nontemporal_store(fetch(pass), q); else *q = fetch(pass);
+            const u32x4_t sv = fetch(pass);
+            if (AM_GEMM_NT) __builtin_nontemporal_store(sv, q); else *q = sv;
+            if (prow) emit_row_part(sv, prow + (int64_t)pass * 32 * nparts, pwriter);
           }
         }
       } else {
@@ -597,6 +641,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_bf16_kernel(am_gemm_args p, in
 // ===========================================================================
 constexpr int HT_BYTES = 128 * BK * 2;         // one half-tile (16 KiB)
 constexpr int PBUF_BYTES = 4 * HT_BYTES;       // [TA0 | TA1 | TB0 | TB1] (64 KiB); two buffers = 128 KiB
+// behind the two buffers: the operands of a folded LayerNorm for this tile - (mean, rstd) of its 256 rows (2 KiB), colsum and d of its
+// 256 columns (1 KiB each) - fetched by LDS-DMA before the prologue, read in the epilogue (they cost 1.7 us of exposed load latency
+// per tile when the epilogue fetched them itself: profiles/r04s)
+constexpr int FOLD_OFF = 2 * PBUF_BYTES;
+constexpr int SMEM2PP_BYTES = FOLD_OFF + 4096;
 
 #define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -661,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       bv[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bv[ni] = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + wn * 64 + ni * 16 + l4 * 4, p.N - 4));
+      if (p.bias && !p.ln_stats) bv[ni] = *reinterpret_cast<const f32x4_t*>(p.bias + min(n0 + wn * 64 + ni * 16 + l4 * 4, p.N - 4));
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(bv[ni]));
@@ -671,6 +720,19 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
       for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = bv[ni];
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (p.ln_stats) {           // folded LayerNorm: this tile's statistics / column sums / d into LDS, one dword per lane and piece
+    {
+      const int dw = wave * 64 + lane;                              // dword dw of the tile's 256 (mean, rstd) pairs
+      const int row = min(m0 + (dw >> 1), p.M - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.ln_stats + 2 * (int64_t)row + (dw & 1)), (lds_ptr_t)(smem + FOLD_OFF + wave * 256), 4, 0, 0);
+    }
+    {
+      const int idx = (wave & 3) * 64 + lane;
+      const int n = min(n0 + idx, p.N - 1);
+      const float* src = wave < 4 ? p.ln_colsum + n : (p.bias ? p.bias + n : p.ln_colsum + n);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + FOLD_OFF + 2048 + wave * 256), 4, 0, 0);
+    }
+  }
 
   // ---- LDS-DMA sources, in 16-byte units from the operand base (32 bits reach 64 GiB).  Piece pc of half-tile h covers
   // rows pc*64 + wave*8 + (lane >> 3) of the half; the lane fetches the unit that belongs at its lane-linear LDS slot.
@@ -791,6 +853,28 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
   ResidualPrefetch pre;
   pre.on = false;
   if constexpr (!HP) residual_prefetch(p, tid, m0, n0, pre);       // 16 loads in flight under the staging pass
+  if (p.ln_stats) {
+    // LayerNorm folded into this linear (am_gemm_args.ln_stats): the accumulators hold x W'^T for the UN-normalised rows x;
+    // row r's output is rstd_r (acc - mean_r colsum_n) + d_n, two FMAs per element on statistics read once per tile.
+    // (the operands were DMA'd behind the ring at kernel start; the vmcnt(0) + barrier in front of this point covers them)
+    f32x4_t cs[4], dv[4];
+    const float* fold = reinterpret_cast<const float*>(smem + FOLD_OFF);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = wn * 64 + ni * 16 + l4 * 4;
+      cs[ni] = *reinterpret_cast<const f32x4_t*>(fold + 512 + nl);
+      dv[ni] = p.bias ? *reinterpret_cast<const f32x4_t*>(fold + 768 + nl) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      const f32x2_t st = *reinterpret_cast<const f32x2_t*>(fold + 2 * (wm * 128 + mi * 16 + l15));
+      const float nm = -st[0] * st[1];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mi][ni][e] = fmaf(acc[mi][ni][e], st[1], fmaf(nm, cs[ni][e], dv[ni][e]));
+    }
+  }
   unsigned char* stage = smem;
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi)
@@ -843,6 +927,9 @@ static int gemm_skew_units(int rounds) {
   return rounds >= 24 ? 4 : rounds >= 16 ? 3 : rounds >= 12 ? 2 : rounds >= 4 ? 1 : 0;
 }
 
+// am_norm.hip: (mean, M2) of the 256-column slices of rows [row0, row0 + rows) of C, into part [row][ceil(N / 256)][2]
+int am_row_part(const bf16_t* Cmat, int ldc, int64_t row0, int64_t rows, int N, float* part, void* stream);
+
 extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_gemm_bf16: null args");
   AM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "am_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -855,15 +942,26 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
            "am_gemm_bf16: leading dimensions must be multiples of 8 elements (16 B)");
   AM_CHECK(((uintptr_t)a->A1 | (uintptr_t)a->W | (uintptr_t)a->C | (uintptr_t)a->A2 | (uintptr_t)a->residual) % 16 == 0,
            "am_gemm_bf16: operands must be 16-byte aligned");
+  if (a->ln_stats) {
+    AM_CHECK(a->ln_colsum != nullptr, "am_gemm_bf16: ln_stats without ln_colsum");
+    AM_CHECK(a->A2 == nullptr && a->a_G == 0, "am_gemm_bf16: a folded LayerNorm needs one A operand with the identity row map");
+    AM_CHECK(!(a->act & 0x200), "am_gemm_bf16: the round-1 lockstep kernel has no folded-LayerNorm epilogue");
+    AM_CHECK(((uintptr_t)a->ln_stats % 8 == 0) && ((uintptr_t)a->ln_colsum % 16 == 0) && (a->bias == nullptr || (uintptr_t)a->bias % 16 == 0) &&
+             a->N % 4 == 0, "am_gemm_bf16: ln_stats / ln_colsum / bias misaligned");
+  }
+  if (a->ln_part) {
+    AM_CHECK(a->c_G == 0, "am_gemm_bf16: ln_part needs the identity C row map");
+    AM_CHECK((uintptr_t)a->ln_part % 8 == 0, "am_gemm_bf16: ln_part misaligned");
+  }
   AM_ONCE_PER_DEVICE({
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_bf16_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2PP_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2PP_BYTES));
   });
   // act bit 8 (0x100) forces the 128x128 register-staged kernel (tests compare the two tilings); bit 9 (0x200) the round-1
   // lockstep main loop of the 256x256 tile (same-box A/B against the ping-pong loop)
@@ -879,6 +977,11 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   const bool big = !force_small && args.N >= 8 && args.M >= 1 &&
                    (force_big || (args.N >= 256 && args.M >= 1024 && (int64_t)ceil_div(args.M, B2) * ceil_div(args.N, B2) >= 192));
   args.act |= abl;          // kernels test `act & 0xff`; bits 11 / 12 are the store / residual timing ablations
+  // ln_part: full 256-row tiles of the ping-pong kernel write their slices from the store loop (N % 256 == 0); every other row -
+  // edge tiles, the 128x128 kernel's rows, the lockstep kernel - gets them from am_row_part below, reading C back
+  float* const ln_part = args.ln_part;
+  int64_t part_done = 0;                                       // rows [0, part_done) are covered by the fused epilogue
+  args.ln_part = nullptr;
   if (big && (abl >> 13) == 0) {
     // start skew per XCD in units of 1.5 us: the more rounds of workgroups a GEMM has, the better the 7-unit tail amortises
     // (24-32 rounds: 6 us per XCD; 8 rounds: 1.5 us); act bits 13-15 = 7 turn it off (A/B runs)
@@ -892,12 +995,19 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
     const int rem = args.M % B2;
     const int m_main = (rem != 0 && rem <= 128 && args.M > 8 * B2) ? args.M - rem : args.M;
     const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
-    if (legacy)
+    if (legacy) {
       hipLaunchKernelGGL(gemm256_bf16_kernel, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
                          (hipStream_t)stream, args, tiles_m, tiles_n, 0);
-    else
-      hipLaunchKernelGGL(gemm256pp_bf16_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES,
-                         (hipStream_t)stream, args, tiles_m, tiles_n, gemm_subskew() << 20, am_headpost_args{});
+    } else {
+      am_gemm_args main_args = args;
+      if (ln_part && args.N % B2 == 0 && !(args.act & 0x1800)) {
+        main_args.ln_part = ln_part;
+        part_done = (int64_t)(args.M / B2) * B2;               // the kernel emits for tiles with m0 + 256 <= M only
+        if (part_done > m_main) part_done = m_main;
+      }
+      hipLaunchKernelGGL(gemm256pp_bf16_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES,
+                         (hipStream_t)stream, main_args, tiles_m, tiles_n, gemm_subskew() << 20, am_headpost_args{});
+    }
     if (m_main < args.M) {
       const int tn = ceil_div(args.N, BN);
       hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
@@ -908,6 +1018,8 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
                        (hipStream_t)stream, args, tiles_m, tiles_n, 0);
   }
   AM_HIP(hipGetLastError());
+  if (ln_part && part_done < args.M)
+    AM_TRY(am_row_part(args.C, args.ldc, part_done, args.M - part_done, args.N, ln_part, stream));
   return AM_OK;
 }
 
@@ -925,7 +1037,8 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   for (int i = 0; i < hp->nparts; ++i) has_v |= hp->kinds[i] == 2;
   const int rem = g->M % B2;
   const bool tail_split = rem != 0 && rem <= 128 && g->M > 8 * B2;
-  const bool fuse = (g->act & 0xff) == 0 && !g->residual && !g->bias && !g->A2 && g->a_G == 0 && g->c_G == 0 && g->N % 256 == 0 && g->M % 16 == 0 &&
+  AM_CHECK(g->ln_part == nullptr, "am_gemm_headpost_bf16: no row statistics of a head-split output");
+  const bool fuse = (g->act & 0xff) == 0 && !g->residual && (!g->bias || g->ln_stats) && !g->A2 && g->a_G == 0 && g->c_G == 0 && g->N % 256 == 0 && g->M % 16 == 0 &&
                     g->N >= 256 && g->M >= 1024 && (int64_t)ceil_div(g->M, B2) * ceil_div(g->N, B2) >= 192 &&
                     (!has_v || hp->seq_len % 16 == 0) && (!tail_split || rem <= hp->seq_len) && hp->rows % hp->seq_len == 0 &&
                     !(g->act & 0x700) && getenv("ACTIONMESH_AMD_NO_FUSED_QKV") == nullptr;
@@ -935,9 +1048,12 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   }
   AM_CHECK(g->K % BK == 0 && g->K1 == g->K && g->lda1 % 8 == 0 && g->ldw % 8 == 0, "am_gemm_headpost_bf16: bad GEMM operands");
   AM_CHECK(((uintptr_t)g->A1 | (uintptr_t)g->W | (uintptr_t)g->C) % 16 == 0, "am_gemm_headpost_bf16: operands must be 16-byte aligned");
+  if (g->ln_stats)
+    AM_CHECK(g->ln_colsum && (uintptr_t)g->ln_stats % 8 == 0 && (uintptr_t)g->ln_colsum % 16 == 0 && (g->bias == nullptr || (uintptr_t)g->bias % 16 == 0),
+             "am_gemm_headpost_bf16: ln_stats / ln_colsum / bias missing or misaligned");
   AM_TRY(am_head_post_check(hp));
   AM_ONCE_PER_DEVICE({
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2PP_BYTES));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
   });
   am_gemm_args args = *g;
@@ -950,7 +1066,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   }
   am_gemm_args main_args = args;
   main_args.M = m_main;                      // the fused epilogue bounds its rows by M: the main grid owns [0, m_main)
-  hipLaunchKernelGGL(gemm256pp_bf16_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), SMEM2_BYTES, (hipStream_t)stream, main_args, tiles_m,
+  hipLaunchKernelGGL(gemm256pp_bf16_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES, (hipStream_t)stream, main_args, tiles_m,
                      tiles_n, gemm_subskew() << 20, *hp);
   if (m_main < args.M) {                     // the remainder rows: plain linear into X, then the head split of exactly those rows
     const int tn = ceil_div(args.N, BN);

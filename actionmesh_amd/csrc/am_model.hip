@@ -15,6 +15,7 @@
 #include "am_common.h"
 
 int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream);    // am_elementwise.hip
+int am_add_bias_rows_stats(bf16_t* h, const float* bias, int64_t rows, int C, float eps, float* stats, void* stream);   // am_norm.hip
 
 // diagnostic trace point (am_common.h am_trace): a checksum of `bytes` at `ptr` behind the kernel that has just been enqueued
 #define TR(stage, layer, ptr, bytes) do { if (am_trace_on()) am_trace((stage) * 100 + (layer), (ptr), (size_t)(bytes), (void*)st); } while (0)
@@ -32,6 +33,10 @@ struct am_layer {
   float *ln_f_w = nullptr, *ln_f_b = nullptr, *ln_k_w = nullptr, *ln_k_b = nullptr;
   float *s_nq = nullptr, *s_nk = nullptr, *x_nq = nullptr, *x_nk = nullptr;
   bf16_t *kx = nullptr, *vtx = nullptr;   // cross-attention K / V^T cache
+  // the three linears that sit behind a LayerNorm (block.py:138 norm_s_attn -> to_q|k|v, :146 norm_x_attn -> to_q, :152 norm_ff ->
+  // ff.net.0) with the norm folded in (am_ln_fold_weight): W (.) gamma, its column sums, and W beta + bias
+  bf16_t *wf_qkv = nullptr, *wf_xq = nullptr, *wf_ff1 = nullptr;
+  float *cs_qkv = nullptr, *d_qkv = nullptr, *cs_xq = nullptr, *d_xq = nullptr, *cs_ff1 = nullptr, *d_ff1 = nullptr;
 };
 
 struct am_model {
@@ -77,6 +82,12 @@ struct am_model {
   bool local_done = false;     // am_layer_attn_local ran for the layer in flight
   bf16_t *xb = nullptr, *te0 = nullptr, *te1 = nullptr, *ctxb = nullptr, *kvtmp = nullptr;
   float *tdev = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+  // Folded LayerNorms: norm_s_attn / norm_x_attn / norm_ff are never launched and their outputs never exist in HBM.
+  // INVARIANT while ln_fold is on: between the kernels of a forward, ln_stats[r] = (mean, rstd) of row r of the current residual
+  // stream buffer (h->hsrc / h->hwork) - written by whoever wrote the rows: the producer GEMM's store loop through ln_part +
+  // am_row_stats_finalize, the norm_skip LayerNorm, or am_row_stats_bf16 for rows no GEMM produced.
+  bool ln_fold = true, folds_ready = false, ln_recompute = false;
+  float *ln_stats = nullptr, *ln_part = nullptr;
 
   // per-window / per-forward state
   std::vector<uint8_t> ctx_zero;   // am_set_branch_hints: batch rows whose context is identically zero
@@ -221,7 +232,7 @@ void build_expected(am_model* m) {
 int gemm(hipStream_t st, const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, const bf16_t* res,
          bf16_t* Cp, int ldc, int64_t M, int N, int K, int act, const bf16_t* A2 = nullptr, int lda2 = 0, int K1 = 0,
          int aG = 0, int ags = 0, int aoff = 0, int cG = 0, int cgs = 0, int coff = 0) {
-  am_gemm_args g;
+  am_gemm_args g = {};
   g.A1 = A; g.lda1 = lda; g.K1 = A2 ? K1 : K;
   g.A2 = A2; g.lda2 = lda2;
   g.W = W; g.ldw = ldw; g.bias = bias; g.residual = res; g.C = Cp; g.ldc = ldc;
@@ -229,6 +240,26 @@ int gemm(hipStream_t st, const bf16_t* A, int lda, const bf16_t* W, int ldw, con
   g.a_G = aG; g.a_gs = ags; g.a_off = aoff;
   g.c_G = cG; g.c_gs = cgs; g.c_off = coff;
   return am_gemm_bf16(&g, st);
+}
+
+int prepare_folds(am_model* m, hipStream_t st) {
+  const int C = m->C, F = m->F;
+  for (am_layer& l : m->layers) {
+    AM_TRY(am_ln_fold_weight(l.w_qkv, l.ln_s_w, l.ln_s_b, nullptr, l.wf_qkv, l.cs_qkv, l.d_qkv, 3 * C, C, st));
+    AM_TRY(am_ln_fold_weight(l.w_xq, l.ln_x_w, l.ln_x_b, nullptr, l.wf_xq, l.cs_xq, l.d_xq, C, C, st));
+    AM_TRY(am_ln_fold_weight(l.w_ff1, l.ln_f_w, l.ln_f_b, l.b_ff1, l.wf_ff1, l.cs_ff1, l.d_ff1, F, C, st));
+  }
+  m->folds_ready = true;
+  return AM_OK;
+}
+
+// (mean, rstd) of rows [r0, r0 + nr) of the residual stream from the slices a producer GEMM left in ln_part
+// (x = the buffer the rows live in; ACTIONMESH_AMD_LN_STATS=recompute reads them back instead - same bits by construction
+// (canonical statistics, am_common.h), which tests/test_denoiser_gpu.py asserts on whole forwards)
+int finalize_stats(am_model* h, const bf16_t* x, int64_t r0, int64_t nr, hipStream_t st) {
+  if (h->ln_recompute) return am_row_stats_bf16(x + r0 * h->C, h->ln_stats + 2 * r0, nr, h->C, 1e-5f, st);
+  const int np = ceil_div(h->C, 256);
+  return am_row_stats_finalize(h->ln_part + 2 * r0 * np, np, h->C, h->ln_stats + 2 * r0, nr, 1e-5f, st);
 }
 
 }  // namespace
@@ -289,6 +320,9 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
       A_(dev_alloc_t(m, &l.w_skip, 2 * C * C)); A_(dev_alloc_t(m, &l.b_skip, C));
       A_(dev_alloc_t(m, &l.ln_k_w, C)); A_(dev_alloc_t(m, &l.ln_k_b, C));
     }
+    A_(dev_alloc_t(m, &l.wf_qkv, 3 * C * C)); A_(dev_alloc_t(m, &l.cs_qkv, 3 * C)); A_(dev_alloc_t(m, &l.d_qkv, 3 * C));
+    A_(dev_alloc_t(m, &l.wf_xq, C * C)); A_(dev_alloc_t(m, &l.cs_xq, C)); A_(dev_alloc_t(m, &l.d_xq, C));
+    A_(dev_alloc_t(m, &l.wf_ff1, F * C)); A_(dev_alloc_t(m, &l.cs_ff1, F)); A_(dev_alloc_t(m, &l.d_ff1, F));
     A_(dev_alloc_t(m, &l.kx, (size_t)BT * m->H * Spad * HD));
     A_(dev_alloc_t(m, &l.vtx, (size_t)BT * m->H * HD * Spad));
   }
@@ -311,6 +345,13 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
   A_(dev_alloc_t(m, &m->tdev, (size_t)BT));
   A_(dev_alloc_t(m, &m->ctxb, (size_t)BT * m->maxS * Dc)); A_(dev_alloc_t(m, &m->kvtmp, (size_t)BT * m->maxS * 2 * C));
   A_(dev_alloc_t(m, &m->rope_cos, (size_t)BT * 64)); A_(dev_alloc_t(m, &m->rope_sin, (size_t)BT * 64));
+  A_(dev_alloc_t(m, &m->ln_stats, R * 2)); A_(dev_alloc_t(m, &m->ln_part, R * 2 * (size_t)ceil_div((int)C, 256)));
+  {
+    const char* e = getenv("ACTIONMESH_AMD_LN_FOLD");       // 0: the round-3 sequence (LayerNorm kernel + plain linear), for A/B
+    m->ln_fold = !(e && e[0] == '0');
+    const char* r = getenv("ACTIONMESH_AMD_LN_STATS");
+    m->ln_recompute = r && strcmp(r, "recompute") == 0;
+  }
 #undef A_
   if (st != AM_OK) {
     am_destroy(m);
@@ -356,6 +397,11 @@ extern "C" int am_load_weight(am_handle h, const char* name, const float* host, 
     AM_HIP(hipMemcpy(s.dst, tmp.data(), numel * sizeof(float), hipMemcpyHostToDevice));
   }
   h->loaded.insert(name);
+  h->folds_ready = false;
+  if (h->ln_fold && am_weights_missing(h) == 0) {      // the last key of a state dict: fold the norms into their linears once
+    AM_TRY(prepare_folds(h, nullptr));
+    AM_HIP(hipStreamSynchronize(nullptr));
+  }
   return AM_OK;
 }
 
@@ -493,6 +539,10 @@ static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int
   AM_TRY(gemm(st, h->te1, 4 * C, h->w_t2, 4 * C, h->b_t2, nullptr, h->hwork, C, BT, C, 4 * C, 0, nullptr, 0, 0, 0, 0, 0,
               /*cG*/ 1, /*cgs*/ h->L, /*coff*/ 0));
   TR(23, 0, h->hwork, (size_t)h->R * C * 2);
+  if (h->ln_fold) {
+    if (!h->folds_ready) AM_TRY(prepare_folds(h, st));      // a handle run with part of its state dict (tests): fold what is there
+    AM_TRY(am_row_stats_bf16(h->hwork, h->ln_stats, h->R, C, 1e-5f, st));
+  }
   h->hsrc = h->hwork;
   h->skip_top = 0;
   h->next_layer = 0;
@@ -516,7 +566,8 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
     const bf16_t* sk = h->skip[--h->skip_top];
     AM_TRY(gemm(st, sk, C, l.w_skip, 2 * C, l.b_skip, nullptr, h->z, C, R, C, 2 * C, 0, h->hsrc, C, C));
     TR(1, i, h->z, (size_t)R * C * 2);
-    AM_TRY(am_layernorm_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, st));
+    if (h->ln_fold) AM_TRY(am_layernorm_stats_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, h->ln_stats, st));
+    else AM_TRY(am_layernorm_bf16(h->z, h->hwork, l.ln_k_w, l.ln_k_b, R, C, 1e-5f, st));
     TR(2, i, h->hwork, (size_t)R * C * 2);
     h->hsrc = h->hwork;
   }
@@ -524,10 +575,15 @@ extern "C" int am_layer_pre_attn(am_handle h, int i, void* stream) {
   // self-attention branch runs on row 0 only and am_layer_post_attn copies its result to the other rows
   const bool shared = i == 0 && h->shared_prefix && !h->has_skip(0);
   const int64_t Rs = shared ? R / h->B : R;
-  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, Rs, C, 1e-5f, st));      // block.py:138
-  TR(3, i, h->z, (size_t)Rs * C * 2);
   am_gemm_args gq = {};      // the q | k | v projection (:92-103), fused with the head split below (am_gemm_headpost_bf16)
-  gq.A1 = h->z; gq.lda1 = C; gq.K1 = C; gq.W = l.w_qkv; gq.ldw = C; gq.C = h->qkv; gq.ldc = 3 * C;
+  if (h->ln_fold) {          // norm_s_attn (block.py:138) inside the projection: rows of h, their statistics, W (.) gamma
+    gq.A1 = h->hsrc; gq.W = l.wf_qkv; gq.bias = l.d_qkv; gq.ln_stats = h->ln_stats; gq.ln_colsum = l.cs_qkv;
+  } else {
+    AM_TRY(am_layernorm_bf16(h->hsrc, h->z, l.ln_s_w, l.ln_s_b, Rs, C, 1e-5f, st));      // block.py:138
+    TR(3, i, h->z, (size_t)Rs * C * 2);
+    gq.A1 = h->z; gq.W = l.w_qkv;
+  }
+  gq.lda1 = C; gq.K1 = C; gq.ldw = C; gq.C = h->qkv; gq.ldc = 3 * C;
   gq.M = (int)Rs; gq.N = 3 * C; gq.K = C;
   am_headpost_args hp = {};
   hp.X = h->qkv; hp.ldx = 3 * C; hp.rows = Rs; hp.rows_per_frame = L;
@@ -691,11 +747,21 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
     }
     TR(12, i, h->ao, (size_t)Rs * C * 2);
   }
-  AM_TRY(gemm(st, h->ao, C, l.w_so, C, l.b_so, h->hsrc, h->hwork, C, Rs, C, C, 0));   // to_out + residual (block.py:137)
+  {   // to_out + residual (block.py:137); with the norms folded, its store loop leaves the row statistics of the new h
+    am_gemm_args go = {};
+    go.A1 = h->ao; go.lda1 = C; go.K1 = C; go.W = l.w_so; go.ldw = C; go.bias = l.b_so; go.residual = h->hsrc;
+    go.C = h->hwork; go.ldc = C; go.M = (int)Rs; go.N = C; go.K = C;
+    if (h->ln_fold) go.ln_part = h->ln_part;
+    AM_TRY(am_gemm_bf16(&go, st));
+    if (h->ln_fold) AM_TRY(finalize_stats(h, h->hwork, 0, Rs, st));
+  }
   TR(13, i, h->hwork, (size_t)Rs * C * 2);
   if (shared)
-    for (int b = 1; b < h->B; ++b)
+    for (int b = 1; b < h->B; ++b) {
       AM_HIP(hipMemcpyAsync(h->hwork + (size_t)b * Rs * C, h->hwork, (size_t)Rs * C * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
+      if (h->ln_fold)
+        AM_HIP(hipMemcpyAsync(h->ln_stats + (size_t)b * Rs * 2, h->ln_stats, (size_t)Rs * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
   h->hsrc = h->hwork;
   // ---- cross-attention to the frame's own context tokens (block.py:146-149) ----
   // Batch rows whose context is identically zero (am_set_branch_hints: the unconditional guidance branch) get the exact
@@ -709,13 +775,19 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
       const int64_t r0 = (int64_t)b0 * R1, nr = (int64_t)(b1 - b0) * R1;
       bf16_t* hrun = h->hwork + (size_t)r0 * C;
       if (zero) {
-        AM_TRY(am_add_bias_rows(hrun, l.b_xo, nr, C, st));
+        if (h->ln_fold) AM_TRY(am_add_bias_rows_stats(hrun, l.b_xo, nr, C, 1e-5f, h->ln_stats + 2 * r0, st));
+        else AM_TRY(am_add_bias_rows(hrun, l.b_xo, nr, C, st));
         TR(19, i, hrun, (size_t)nr * C * 2);
       } else {
-        AM_TRY(am_layernorm_bf16(hrun, h->z, l.ln_x_w, l.ln_x_b, nr, C, 1e-5f, st));
-        TR(14, i, h->z, (size_t)nr * C * 2);
         am_gemm_args gx = {};      // cross-attention to_q, fused with its head split
-        gx.A1 = h->z; gx.lda1 = C; gx.K1 = C; gx.W = l.w_xq; gx.ldw = C; gx.C = h->qkv; gx.ldc = C;
+        if (h->ln_fold) {          // norm_x_attn (block.py:146) inside to_q
+          gx.A1 = hrun; gx.W = l.wf_xq; gx.bias = l.d_xq; gx.ln_stats = h->ln_stats + 2 * r0; gx.ln_colsum = l.cs_xq;
+        } else {
+          AM_TRY(am_layernorm_bf16(hrun, h->z, l.ln_x_w, l.ln_x_b, nr, C, 1e-5f, st));
+          TR(14, i, h->z, (size_t)nr * C * 2);
+          gx.A1 = h->z; gx.W = l.w_xq;
+        }
+        gx.lda1 = C; gx.K1 = C; gx.ldw = C; gx.C = h->qkv; gx.ldc = C;
         gx.M = (int)nr; gx.N = C; gx.K = C;
         am_headpost_args hp = {};
         hp.X = h->qkv; hp.ldx = C; hp.rows = nr; hp.seq_len = L; hp.rows_per_frame = L;
@@ -741,20 +813,44 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
         ax.ldo = C; ax.scale = scale; ax.defer_log2 = h->cfg.attn_defer_log2;
         AM_TRY(am_attention_bf16(&ax, st));
         TR(17, i, h->ao, (size_t)nr * C * 2);
-        AM_TRY(gemm(st, h->ao, C, l.w_xo, C, l.b_xo, hrun, hrun, C, nr, C, C, 0));
+        {
+          am_gemm_args go = {};
+          go.A1 = h->ao; go.lda1 = C; go.K1 = C; go.W = l.w_xo; go.ldw = C; go.bias = l.b_xo; go.residual = hrun;
+          go.C = hrun; go.ldc = C; go.M = (int)nr; go.N = C; go.K = C;
+          if (h->ln_fold) go.ln_part = h->ln_part + 2 * r0 * ceil_div(C, 256);
+          AM_TRY(am_gemm_bf16(&go, st));
+          if (h->ln_fold) AM_TRY(finalize_stats(h, h->hwork, r0, nr, st));
+        }
         TR(18, i, hrun, (size_t)nr * C * 2);
       }
       b0 = b1;
     }
   }
   // ---- feed-forward (block.py:152; diffusers FeedForward "gelu") ------------------
-  AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_f_w, l.ln_f_b, R, C, 1e-5f, st));
-  TR(20, i, h->z, (size_t)R * C * 2);
-  AM_TRY(gemm(st, h->z, C, l.w_ff1, C, l.b_ff1, nullptr, h->ffh, F, R, F, C, 1));
+  if (h->ln_fold) {          // norm_ff (block.py:152) inside ff.net.0
+    am_gemm_args g1 = {};
+    g1.A1 = h->hwork; g1.lda1 = C; g1.K1 = C; g1.W = l.wf_ff1; g1.ldw = C; g1.bias = l.d_ff1; g1.C = h->ffh; g1.ldc = F;
+    g1.M = (int)R; g1.N = F; g1.K = C; g1.act = 1; g1.ln_stats = h->ln_stats; g1.ln_colsum = l.cs_ff1;
+    AM_TRY(am_gemm_bf16(&g1, st));
+  } else {
+    AM_TRY(am_layernorm_bf16(h->hwork, h->z, l.ln_f_w, l.ln_f_b, R, C, 1e-5f, st));
+    TR(20, i, h->z, (size_t)R * C * 2);
+    AM_TRY(gemm(st, h->z, C, l.w_ff1, C, l.b_ff1, nullptr, h->ffh, F, R, F, C, 1));
+  }
   TR(21, i, h->ffh, (size_t)R * F * 2);
   bf16_t* dst = h->hwork;
   if (i < h->NL / 2) dst = h->skip[h->skip_top++];     // temporal_denoiser.py:231-232 (kept, not copied)
-  AM_TRY(gemm(st, h->ffh, F, l.w_ff2, F, l.b_ff2, h->hwork, dst, C, R, C, F, 0));
+  {
+    // the next reader of the row statistics is the next block's norm_s_attn - unless that block starts with its skip linear + norm_skip
+    // (which writes its own) or there is no next block (norm_out runs as a LayerNorm kernel in front of the 64-column proj_out)
+    const bool want = h->ln_fold && i + 1 < h->NL && !h->has_skip(i + 1);
+    am_gemm_args g2 = {};
+    g2.A1 = h->ffh; g2.lda1 = F; g2.K1 = F; g2.W = l.w_ff2; g2.ldw = F; g2.bias = l.b_ff2; g2.residual = h->hwork;
+    g2.C = dst; g2.ldc = C; g2.M = (int)R; g2.N = C; g2.K = F;
+    if (want) g2.ln_part = h->ln_part;
+    AM_TRY(am_gemm_bf16(&g2, st));
+    if (want) AM_TRY(finalize_stats(h, dst, 0, R, st));
+  }
   TR(22, i, dst, (size_t)R * C * 2);
   h->hsrc = dst;
   h->next_layer = i + 1;

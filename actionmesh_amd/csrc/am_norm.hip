@@ -8,10 +8,39 @@ namespace {
 // FP32LayerNorm (diffusers) / nn.LayerNorm: block.py:64,83,98,107 and
 // temporal_denoiser.py:107.  One wave per row; lane holds NCH chunks of 8.
 // ---------------------------------------------------------------------------
+// Canonical (am_common.h) row statistics from the LayerNorm kernels' register layout: lane holds the 8-value groups (j * 64 + lane),
+// i.e. group lane & 31 of slice 2 j + (lane >> 5).  C % 256 == 0.
+template <int NCH>
+__device__ __forceinline__ void canonical_row_stats(const float (&v)[NCH][8], int C, float eps, float& mean, float& rstd) {
+  const int np = C >> 8;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (2 * j < np) {                       // wave-uniform
+      float pm, pq;
+      row_part8(v[j], pm, pq);
+      float half_n = 4.f;
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+        const float om = __shfl_xor(pm, off), oq = __shfl_xor(pq, off);
+        row_part_merge_equal(pm, pq, om, oq, half_n);
+        half_n *= 2.f;
+      }
+      const float m_lo = __shfl(pm, 0), q_lo = __shfl(pq, 0), m_hi = __shfl(pm, 32), q_hi = __shfl(pq, 32);
+      row_stats_merge(n, mu, m2, 256.f, m_lo, q_lo);
+      if (2 * j + 1 < np) row_stats_merge(n, mu, m2, 256.f, m_hi, q_hi);
+    }
+  }
+  mean = mu;
+  rstd = row_stats_rstd(n, m2, eps);
+}
+
+// `stats` (optional, [rows][2] fp32): (mean, rstd) for a linear that absorbs the NEXT LayerNorm (am_gemm_args.ln_stats) - of
+// the rows of x when y == nullptr (statistics only: one read of x, nothing else), of the bf16-rounded OUTPUT rows otherwise.
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        int64_t rows, int C, float eps) {
+                                                        int64_t rows, int C, float eps, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -53,7 +82,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
   const float rstd = rsqrtf(sq / (float)C + eps);
+  if (y == nullptr) {                   // statistics only: the canonical form when the row is whole slices, the two-pass values otherwise
+    float cm = mean, cr = rstd;
+    if ((C & 255) == 0) canonical_row_stats<NCH>(v, C, eps, cm, cr);
+    if (lane == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * row) = f32x2_t{cm, cr};
+    return;
+  }
   bf16_t* yr = y + row * C;
+  float osum = 0.f;
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     const int col = (j * 64 + lane) * 8;
@@ -72,7 +108,167 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int e = 0; e < 4; ++e) u[e] = pack_bf2(o[2 * e], o[2 * e + 1]);
       *reinterpret_cast<u32x4_t*>(yr + col) = u;
+      if (stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[j][2 * e] = bflo(u[e]);
+          v[j][2 * e + 1] = bfhi(u[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) osum += v[j][e];
+      }
     }
+  }
+  if (stats) {          // statistics of the rows just written (v now holds the bf16-rounded outputs)
+    float om, orstd;
+    if ((C & 255) == 0) {
+      canonical_row_stats<NCH>(v, C, eps, om, orstd);
+    } else {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) osum += __shfl_xor(osum, off);
+      om = osum / (float)C;
+      float osq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int col = (j * 64 + lane) * 8;
+        if (col < C) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[j][e] - om;
+            osq += d * d;
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) osq += __shfl_xor(osq, off);
+      orstd = rsqrtf(osq / (float)C + eps);
+    }
+    if (lane == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * row) = f32x2_t{om, orstd};
+  }
+}
+
+// am_add_bias_rows (am_elementwise.hip: h += to_out bias, the exact result of a cross-attention branch over an all-zero context) in the
+// LayerNorm kernels' row layout, leaving the canonical (mean, rstd) of the rows it writes - one pass over h instead of two.
+template <int NCH>
+__global__ __launch_bounds__(256) void add_bias_rows_stats_kernel(bf16_t* __restrict__ h, const float* __restrict__ bias, int64_t rows, int C,
+                                                                  float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  bf16_t* hr = h + row * C;
+  float v[NCH][8];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (j * 64 + lane) * 8;
+    if (col < C) {
+      u32x4_t u = *reinterpret_cast<const u32x4_t*>(hr + col);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + col), b1 = *reinterpret_cast<const f32x4_t*>(bias + col + 4);
+      u[0] = pack_bf2(bflo(u[0]) + rbf(b0[0]), bfhi(u[0]) + rbf(b0[1]));
+      u[1] = pack_bf2(bflo(u[1]) + rbf(b0[2]), bfhi(u[1]) + rbf(b0[3]));
+      u[2] = pack_bf2(bflo(u[2]) + rbf(b1[0]), bfhi(u[2]) + rbf(b1[1]));
+      u[3] = pack_bf2(bflo(u[3]) + rbf(b1[2]), bfhi(u[3]) + rbf(b1[3]));
+      *reinterpret_cast<u32x4_t*>(hr + col) = u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[j][2 * e] = bflo(u[e]); v[j][2 * e + 1] = bfhi(u[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    }
+  }
+  float mean, rstd;
+  canonical_row_stats<NCH>(v, C, eps, mean, rstd);
+  if (lane == 0) *reinterpret_cast<f32x2_t*>(stats + 2 * row) = f32x2_t{mean, rstd};
+}
+
+// (mean, M2) of every 256-column slice of rows [row0, row0 + rows) of X - the rows a producer GEMM's store loop did not cover
+// (am_gemm_args.ln_part; emit_row_part in am_gemm.hip computes the same pairs in flight).  One wave per row, 4 columns per lane.
+__global__ __launch_bounds__(256) void row_part_kernel(const bf16_t* __restrict__ X, int ldx, int64_t row0, int64_t rows, int N,
+                                                       float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t row = row0 + r;
+  const int nparts = (N + 255) >> 8, nfull = N >> 8;
+  // whole slices, two per trip (one per half-wave): the canonical groups and tree of am_common.h
+  for (int t = 0; 2 * t < nfull; ++t) {
+    const int sl = 2 * t + (lane >> 5);
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (sl < nfull) {
+      const u32x4_t u = *reinterpret_cast<const u32x4_t*>(X + row * ldx + sl * 256 + (lane & 31) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[2 * e] = bflo(u[e]); x[2 * e + 1] = bfhi(u[e]); }
+    }
+    float pm, pq;
+    row_part8(x, pm, pq);
+    float half_n = 4.f;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const float om = __shfl_xor(pm, off), oq = __shfl_xor(pq, off);
+      row_part_merge_equal(pm, pq, om, oq, half_n);
+      half_n *= 2.f;
+    }
+    if ((lane & 31) == 0 && sl < nfull) *reinterpret_cast<f32x2_t*>(part + 2 * (row * nparts + sl)) = f32x2_t{pm, pq};
+  }
+  if (nfull < nparts) {          // a short last slice (N % 256 != 0: no GEMM store loop writes these): plain two-pass, 4 columns per lane
+    const int j = nfull;
+    const int col = j * 256 + lane * 4;
+    const int cnt = N - j * 256;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool in = col < N;                 // N % 8 == 0 and col % 4 == 0: a lane's four columns are in or out together
+    if (in) {
+      const u32x2_t u = *reinterpret_cast<const u32x2_t*>(X + row * ldx + col);
+      x[0] = bflo(u[0]); x[1] = bfhi(u[0]); x[2] = bflo(u[1]); x[3] = bfhi(u[1]);
+    }
+    float sum = (x[0] + x[1]) + (x[2] + x[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)cnt;
+    float sq = 0.f;
+    if (in) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = x[e] - mean; sq += d * d; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) *reinterpret_cast<f32x2_t*>(part + 2 * (row * nparts + j)) = f32x2_t{mean, sq};
+  }
+}
+
+// Merge the slices of a row: running (n, mean, M2) += (n_j, mean_j, M2_j) by Chan et al.'s update.  One thread per row.
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ stats,
+                                                                 int64_t rows, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const f32x2_t* p = reinterpret_cast<const f32x2_t*>(part) + row * nparts;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int j = 0; j < nparts; ++j) {
+    const f32x2_t q = p[j];
+    row_stats_merge(n, mean, m2, (float)min(256, C - j * 256), q[0], q[1]);
+  }
+  *reinterpret_cast<f32x2_t*>(stats + 2 * row) = f32x2_t{mean, row_stats_rstd(n, m2, eps)};
+}
+
+// Weight preparation of a linear that absorbs its LayerNorm (am_ln_fold_weight).  One wave per output row n.
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             bf16_t* __restrict__ Wf, float* __restrict__ colsum, float* __restrict__ dvec,
+                                                             int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float cs = 0.f, dd = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = bf2f(W[(int64_t)n * K + k]);
+    const bf16_t wf = f2bf(w * gamma[k]);
+    Wf[(int64_t)n * K + k] = wf;
+    cs += bf2f(wf);
+    dd = fmaf(w, beta[k], dd);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { cs += __shfl_xor(cs, off); dd += __shfl_xor(dd, off); }
+  if (lane == 0) {
+    colsum[n] = cs;
+    dvec[n] = dd + (bias ? bias[n] : 0.f);
   }
 }
 
@@ -197,6 +393,19 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
   }
 }
 
+int launch_layernorm(const uint16_t* x, uint16_t* y, const float* w, const float* b, int64_t rows, int C, float eps, float* stats,
+                     void* stream) {
+  const dim3 grid(ceil_div(rows, 4)), block(256);
+  const int nch = ceil_div(C, 512);
+  hipStream_t s = (hipStream_t)stream;
+  if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, y, w, b, rows, C, eps, stats);
+  else if (nch <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, y, w, b, rows, C, eps, stats);
+  else if (nch <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, y, w, b, rows, C, eps, stats);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, y, w, b, rows, C, eps, stats);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 }  // namespace
 
 extern "C" int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,
@@ -204,13 +413,67 @@ extern "C" int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w,
   AM_CHECK(x && y && w && b, "am_layernorm_bf16: null operand");
   AM_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, "am_layernorm_bf16: bad shape rows=%lld C=%d", (long long)rows, C);
   AM_CHECK(((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) % 16 == 0, "am_layernorm_bf16: operands misaligned");
+  return launch_layernorm(x, y, w, b, rows, C, eps, nullptr, stream);
+}
+
+extern "C" int am_layernorm_stats_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,
+                                       int64_t rows, int C, float eps, float* stats_y, void* stream) {
+  AM_CHECK(x && y && w && b && stats_y, "am_layernorm_stats_bf16: null operand");
+  AM_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, "am_layernorm_stats_bf16: bad shape rows=%lld C=%d", (long long)rows, C);
+  AM_CHECK(((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) % 16 == 0 && (uintptr_t)stats_y % 8 == 0,
+           "am_layernorm_stats_bf16: operands misaligned");
+  return launch_layernorm(x, y, w, b, rows, C, eps, stats_y, stream);
+}
+
+extern "C" int am_row_stats_bf16(const uint16_t* x, float* stats, int64_t rows, int C, float eps, void* stream) {
+  AM_CHECK(x && stats, "am_row_stats_bf16: null operand");
+  AM_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, "am_row_stats_bf16: bad shape rows=%lld C=%d", (long long)rows, C);
+  AM_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)stats % 8 == 0, "am_row_stats_bf16: operands misaligned");
+  return launch_layernorm(x, nullptr, nullptr, nullptr, rows, C, eps, stats, stream);
+}
+
+int am_add_bias_rows(bf16_t* h, const float* bias, int64_t rows, int C, void* stream);     // am_elementwise.hip
+
+// internal (am_model.hip): h += bias over `rows` rows and the rows' (mean, rstd) into stats
+int am_add_bias_rows_stats(bf16_t* h, const float* bias, int64_t rows, int C, float eps, float* stats, void* stream) {
+  if (rows <= 0) return AM_OK;
+  if (C % 256 != 0 || C > 4096) {
+    AM_TRY(am_add_bias_rows(h, bias, rows, C, stream));
+    return am_row_stats_bf16(h, stats, rows, C, eps, stream);
+  }
   const dim3 grid(ceil_div(rows, 4)), block(256);
-  const int nch = ceil_div(C, 512);
+  const int nch = C / 512;
   hipStream_t s = (hipStream_t)stream;
-  if (nch <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, y, w, b, rows, C, eps);
-  else if (nch <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, y, w, b, rows, C, eps);
-  else if (nch <= 4) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, y, w, b, rows, C, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, y, w, b, rows, C, eps);
+  if (nch <= 1) hipLaunchKernelGGL(add_bias_rows_stats_kernel<1>, grid, block, 0, s, h, bias, rows, C, eps, stats);
+  else if (nch <= 2) hipLaunchKernelGGL(add_bias_rows_stats_kernel<2>, grid, block, 0, s, h, bias, rows, C, eps, stats);
+  else if (nch <= 4) hipLaunchKernelGGL(add_bias_rows_stats_kernel<4>, grid, block, 0, s, h, bias, rows, C, eps, stats);
+  else hipLaunchKernelGGL(add_bias_rows_stats_kernel<8>, grid, block, 0, s, h, bias, rows, C, eps, stats);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+int am_row_part(const bf16_t* Cmat, int ldc, int64_t row0, int64_t rows, int N, float* part, void* stream) {
+  if (rows <= 0) return AM_OK;
+  hipLaunchKernelGGL(row_part_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, Cmat, ldc, row0, rows, N, part);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_row_stats_finalize(const float* part, int nparts, int C, float* stats, int64_t rows, float eps, void* stream) {
+  AM_CHECK(part && stats, "am_row_stats_finalize: null operand");
+  AM_CHECK(rows > 0 && C > 0 && nparts == (C + 255) / 256, "am_row_stats_finalize: bad shape rows=%lld C=%d nparts=%d", (long long)rows, C, nparts);
+  AM_CHECK(((uintptr_t)part | (uintptr_t)stats) % 8 == 0, "am_row_stats_finalize: operands misaligned");
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts, C, stats, rows, eps);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
+extern "C" int am_ln_fold_weight(const uint16_t* W, const float* gamma, const float* beta, const float* bias, uint16_t* Wf, float* colsum,
+                                 float* d, int N, int K, void* stream) {
+  AM_CHECK(W && gamma && beta && Wf && colsum && d, "am_ln_fold_weight: null operand");
+  AM_CHECK(N > 0 && K > 0, "am_ln_fold_weight: bad shape N=%d K=%d", N, K);
+  hipLaunchKernelGGL(ln_fold_weight_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(W), gamma,
+                     beta, bias, reinterpret_cast<bf16_t*>(Wf), colsum, d, N, K);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

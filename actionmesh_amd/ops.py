@@ -71,11 +71,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          a2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
          M: Optional[int] = None, force_small: bool = False, legacy: bool = False,
-         force_big: bool = False, ablate: int = 0) -> torch.Tensor:
+         force_big: bool = False, ablate: int = 0,
+         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, ln_part: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
-    a_map / c_map = (G, group_stride, offset) row maps (G=0: identity)."""
+    a_map / c_map = (G, group_stride, offset) row maps (G=0: identity).
+    ln = (stats (M, 2) fp32, colsum (N,) fp32): the LayerNorm of `a` folded into the linear (w, bias from ln_fold_weight; see
+    am_gemm_args in include/actionmesh_amd.h).  ln_part (M, ceil(N / 256), 2) fp32: receives the per-slice (mean, M2) of the output rows."""
     _need(a, H16, "a"); _need(w, a.dtype, "w")
     K1 = a.shape[1]
     K = w.shape[1]
@@ -103,17 +106,64 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0xF800)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
+    if ln is not None:
+        g.ln_stats = _need(ln[0], torch.float32, "ln stats").data_ptr()
+        g.ln_colsum = _need(ln[1], torch.float32, "ln colsum").data_ptr()
+        assert ln[0].numel() >= 2 * M and ln[1].numel() == N
+    if ln_part is not None:
+        _need(ln_part, torch.float32, "ln_part")
+        assert ln_part.numel() >= 2 * M * ((N + 255) // 256)
+        g.ln_part = ln_part.data_ptr()
     _launch(a, _fn(a, "am_gemm_bf16"), "am_gemm_bf16", C.byref(g))
     return out
 
 
+def row_stats(x: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(mean, rstd) per row of x (rows, C): fp32 (rows, 2) - the statistics layernorm() uses, for gemm(..., ln=...)."""
+    _need(x, H16, "x")
+    Cdim = x.shape[-1]
+    rows = x.numel() // Cdim
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    _launch(x, _fn(x, "am_row_stats_bf16"), "am_row_stats_bf16", x.data_ptr(), _need(out, torch.float32, "out").data_ptr(), rows, Cdim, eps)
+    return out
+
+
+def row_stats_finalize(part: torch.Tensor, Cdim: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None, kind=torch.bfloat16) -> torch.Tensor:
+    """part (rows, ceil(Cdim / 256), 2) fp32 pairs (mean, M2) of 256-column slices (gemm(..., ln_part=...)) -> (rows, 2) (mean, rstd)."""
+    _need(part, torch.float32, "part")
+    rows, nparts = part.shape[0], part.shape[1]
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=part.device)
+    _launch(part, _fn(kind, "am_row_stats_finalize"), "am_row_stats_finalize", part.data_ptr(), nparts, Cdim, out.data_ptr(), rows, eps)
+    return out
+
+
+def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """One-time preparation of a linear that absorbs the LayerNorm in front of it: returns (wf, colsum, d) for gemm(a, wf, bias=d,
+    ln=(row_stats(a), colsum)) == gemm(layernorm(a, gamma, beta), w, bias) up to the bf16 rounding of the normalised activation."""
+    _need(w, H16, "w"); _need(gamma, torch.float32, "gamma"); _need(beta, torch.float32, "beta")
+    N, K = w.shape
+    wf = torch.empty_like(w)
+    colsum = torch.empty((N,), dtype=torch.float32, device=w.device)
+    d = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _launch(w, _fn(w, "am_ln_fold_weight"), "am_ln_fold_weight", w.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            _p(_need(bias, torch.float32, "bias")) if bias is not None else None, wf.data_ptr(), colsum.data_ptr(), d.data_ptr(), N, K)
+    return wf, colsum, d
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stats_out (rows, 2) fp32: also receives (mean, rstd) of the OUTPUT rows (for a linear that folds the next LayerNorm)."""
     _need(x, H16, "x"); _need(w, torch.float32, "w"); _need(b, torch.float32, "b")
     Cdim = x.shape[-1]
     rows = x.numel() // Cdim
     if out is None:
         out = torch.empty_like(x)
+    if stats_out is not None:
+        _launch(x, _fn(x, "am_layernorm_stats_bf16"), "am_layernorm_stats_bf16", x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
+                rows, Cdim, eps, _need(stats_out, torch.float32, "stats_out").data_ptr())
+        return out
     _launch(x, _fn(x, "am_layernorm_bf16"), "am_layernorm_bf16", x.data_ptr(), out.data_ptr(), w.data_ptr(), b.data_ptr(),
                                       rows, Cdim, eps)
     return out
@@ -159,7 +209,8 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
                    w_q: Optional[torch.Tensor] = None, w_k: Optional[torch.Tensor] = None,
                    rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, eps: float = 1e-6,
                    out_q: Optional[torch.Tensor] = None, out_k: Optional[torch.Tensor] = None,
-                   out_vt: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None):
+                   out_vt: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None,
+                   bias: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """am_gemm_headpost_bf16: (a @ w.T) -> head split / qk-RMSNorm / RoPE / attention layouts in ONE launch; the arguments of `gemm`
     (no bias, no activation) and of `head_post`.  `x` (rows, N) is the linear's output buffer the un-fused pair would use (only the
     tile grid's remainder rows are written to it).  Returns (Q, K, Vt) like head_post."""
@@ -177,6 +228,11 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
     g.W = w.data_ptr(); g.ldw = w.stride(0)
     g.C = x.data_ptr(); g.ldc = x.stride(0)
     g.M, g.N, g.K = rows, N, K
+    if bias is not None:
+        g.bias = _need(bias, torch.float32, "bias").data_ptr()
+    if ln is not None:       # LayerNorm folded into the projection (gemm's `ln`)
+        g.ln_stats = _need(ln[0], torch.float32, "ln stats").data_ptr()
+        g.ln_colsum = _need(ln[1], torch.float32, "ln colsum").data_ptr()
     h = L.AmHeadPostArgs()
     h.X = x.data_ptr(); h.ldx = x.stride(0)
     h.rows = rows; h.seq_len = seq_len; h.rows_per_frame = rows_per_frame

@@ -191,8 +191,32 @@ typedef struct {
   int32_t act;                 /* 0 none, 1 exact-erf GELU */
   int32_t a_G, a_gs, a_off;
   int32_t c_G, c_gs, c_off;
+  /* LayerNorm folded into the linear that consumes it (block.py:138,146,152: norm -> to_q|k|v / to_q / ff.net.0): with
+   * ln_stats != NULL, A holds the UN-normalised rows x, W holds bf16(W (.) gamma), `bias` holds d = W beta + b,
+   * ln_colsum[n] = sum_k W'[n][k], ln_stats[r] = (mean_r, rstd_r) (am_row_stats_bf16 / am_row_stats_finalize), and
+   *   C = act(rstd_r (x W'^T - mean_r colsum) + d) + residual
+   * - the normalised activation is never written.  Identity A row map, no A2.  am_ln_fold_weight prepares W', colsum, d. */
+  const float* ln_stats;
+  const float* ln_colsum;
+  /* LayerNorm statistics of the OUTPUT rows for the next consumer (written, not read): ln_part [M][ceil(N / 256)] pairs
+   * (mean, M2) of each row's 256-column slice of the bf16-rounded C (after act + residual); am_row_stats_finalize merges them. */
+  float* ln_part;
 } am_gemm_args;
 int am_gemm_bf16(const am_gemm_args* args, void* stream);
+
+/* (mean, rstd) of every row of x [rows][C] bf16, fp32 two-pass statistics (the ones am_layernorm_bf16 uses). */
+int am_row_stats_bf16(const uint16_t* x, float* stats, int64_t rows, int C, float eps, void* stream);
+/* Merge the per-slice (mean, M2) pairs a producer GEMM wrote (am_gemm_args.ln_part, `nparts` = ceil(C / 256) slices of 256
+ * columns, the last one shorter when C % 256 != 0) into (mean, rstd) per row - Chan's pairwise update, no E[x^2] - mean^2 cancellation. */
+int am_row_stats_finalize(const float* part, int nparts, int C, float* stats, int64_t rows, float eps, void* stream);
+/* am_layernorm_bf16 that also writes (mean, rstd) of its bf16-rounded OUTPUT rows to stats_y [rows][2] (block.py:133 -> :138:
+ * norm_skip's output is the input of the next, folded, LayerNorm). */
+int am_layernorm_stats_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,
+                            int64_t rows, int C, float eps, float* stats_y, void* stream);
+/* One-time weight preparation of a folded linear: Wf = bf16(W (.) gamma) [N][K], colsum[n] = sum_k Wf[n][k],
+ * d[n] = sum_k W[n][k] beta[k] + bias[n] (bias may be NULL).  W is the bf16 weight the un-folded linear uses. */
+int am_ln_fold_weight(const uint16_t* W, const float* gamma, const float* beta, const float* bias, uint16_t* Wf, float* colsum,
+                      float* d, int N, int K, void* stream);
 
 /* FP32LayerNorm / nn.LayerNorm (block.py:64,83,98,107; temporal_denoiser.py:107):
  * y = (x-mean)/sqrt(var+eps)*w+b, fp32 statistics, bf16 in/out. C % 8 == 0, C <= 4096. */

@@ -189,8 +189,15 @@ def test_two_rank_frame_sharding_emulated_on_one_gpu(dev, golden_dir, name):
     v = torch.cat([e.end() for e in engines], dim=1)
     torch.cuda.synchronize()
     r = rel(v, ref)
-    print(f"{name}: 2-rank emulated vs unsharded rel-L2 {r:.3e}")
-    assert r < 5e-3
+    ref32 = torch.from_numpy(g["fwd_velocity_fp32"])
+    e_sh, e_un = rel(v.float().cpu(), ref32), rel(ref.float().cpu(), ref32)
+    print(f"{name}: 2-rank emulated vs unsharded rel-L2 {r:.3e}; vs the fp32 reference: sharded {e_sh:.3e}, unsharded {e_un:.3e}")
+    # Two bf16 computations of the same function (the two-pass attention meets other running maxima).  With the LayerNorms folded
+    # into their linears there is no bf16 rounding of the normalised activation to re-align the two runs, so they sit further
+    # apart (6.2e-3; 2.6e-3 with ACTIONMESH_AMD_LN_FOLD=0) while each is exactly as close to the reference's fp32 result
+    # (8.41e-3 / 8.47e-3): the second statement is the one that matters.
+    assert r < 8e-3
+    assert e_sh < 1.05 * e_un
     assert rel(v.float().cpu(), torch.from_numpy(g["fwd_velocity_fp32"])) < 2e-2
 
 
@@ -484,6 +491,38 @@ def test_exact_shortcuts_are_bit_identical(dev, golden_dir, name):
     finally:
         del os.environ["ACTIONMESH_AMD_NO_SHORTCUTS"]
     assert torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_folded_layernorms(dev, golden_dir, name, monkeypatch):
+    """norm_s_attn / norm_x_attn / norm_ff live inside the linears behind them (am_model.hip).  (1) The row statistics a
+    producer GEMM leaves behind are the same BITS as a read-back of the rows (ACTIONMESH_AMD_LN_STATS=recompute) on a whole
+    forward; (2) the round-3 sequence - LayerNorm kernel, bf16 activation, plain linear: ACTIONMESH_AMD_LN_FOLD=0 - differs only
+    by the rounding of that activation, and is no closer to the reference than the folded form."""
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser
+    g, cfg, sd, model, t = _setup(name, golden_dir, dev)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    tt = torch.tensor([float(g["fwd_t"])]).expand(2)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = HipDenoiser(num_tokens_nominal=48, temporal_context_size=4, **CASES[name])
+        m.load_state_dict(sd)
+        m.to(dev).eval()
+        v, _ = m.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), None)
+        for k in env:
+            monkeypatch.delenv(k)
+        return v.float().cpu()
+
+    v = run({})
+    assert torch.equal(v, run({"ACTIONMESH_AMD_LN_STATS": "recompute"}))
+    v0 = run({"ACTIONMESH_AMD_LN_FOLD": "0"})
+    ref32 = torch.from_numpy(g["fwd_velocity_fp32"])
+    print(f"{name}: folded vs un-folded rel-L2 {rel(v, v0):.3e}; vs reference fp32: folded {rel(v, ref32):.3e}, un-folded {rel(v0, ref32):.3e}")
+    assert rel(v, v0) < 8e-3
+    assert rel(v, ref32) < 1.05 * rel(v0, ref32)
 
 
 @pytest.mark.parametrize("name", list(CASES))

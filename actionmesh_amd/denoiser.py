@@ -19,7 +19,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
-from .sharding import FrameShardPlan, gather_frames, sharded_forward
+from .sharding import FrameShardPlan, gather_cfg, gather_frames, gather_latent_frames, sharded_forward
 
 HEAD_DIM = 128
 
@@ -312,6 +312,7 @@ class HipDenoiser(nn.Module):
         self.process_group = process_group
         self.cfg_parallel = cfg_parallel
         self._frame_groups: Dict[int, List] = {}     # cfg_groups -> [ProcessGroup per CFG branch]
+        self._cfg_peer_groups: Dict[int, List] = {}  # cfg_groups -> [ProcessGroup per position inside a CFG group]
         self.register_buffer("_device_probe", torch.zeros(1), persistent=False)
         self._host_sd: Optional[Dict[str, torch.Tensor]] = None
         self._engine: Optional[HipEngine] = None
@@ -368,6 +369,15 @@ class HipDenoiser(nn.Module):
             self._frame_groups[plan.cfg_groups] = [
                 dist.new_group([base[r] for r in plan.frame_group_ranks(g)]) for g in range(plan.cfg_groups)]
         return self._frame_groups[plan.cfg_groups][plan.cfg_rank]
+
+    def _cfg_peer_group(self, plan: FrameShardPlan):
+        """Process group of the ranks that hold the SAME frame shard of the other CFG branches (created collectively once): the
+        only ranks a sampler that keeps its latents sharded has to hear from in a step (forward_host_time(gather=False))."""
+        if plan.cfg_groups not in self._cfg_peer_groups:
+            base = dist.get_process_group_ranks(self.process_group)
+            self._cfg_peer_groups[plan.cfg_groups] = [
+                dist.new_group([base[r] for r in plan.cfg_peer_ranks(i)]) for i in range(plan.group_size)]
+        return self._cfg_peer_groups[plan.cfg_groups][plan.rank % plan.group_size]
 
     def compute_kind(self) -> str:
         """'bf16' or 'f16': the pinned dtype, else the autocast dtype of the calling region (float16 only when the caller asked for it)."""
@@ -435,8 +445,13 @@ class HipDenoiser(nn.Module):
             self._window = None
         return out
 
-    def forward_host_time(self, hidden_states: torch.Tensor, t_bt: List[float]) -> torch.Tensor:
-        """Forward with the masked per-(b,t) diffusion times already on the host."""
+    def forward_host_time(self, hidden_states: torch.Tensor, t_bt: List[float], gather: bool = True) -> torch.Tensor:
+        """Forward with the masked per-(b,t) diffusion times already on the host.
+        `gather=False` (a sampler that keeps its latents sharded across the steps): returns the velocity of ALL batch
+        rows for THIS rank's frames only - (B, T_local, N, D), frames `frame_slice(T, B)` - and reads only those frames of
+        `hidden_states`.  With the batch on one CFG group that is the local result and the step has no velocity collective at
+        all; with the CFG branches split over groups it is one all-gather among the ranks that hold the same frames
+        (1 / frame_world of the bytes of the full gather)."""
         B, T, N, _ = hidden_states.shape
         plan = self._plan(T, B)
         e = self._engine
@@ -449,8 +464,25 @@ class HipDenoiser(nn.Module):
             v_local = e.forward(x_local, t_local)
         else:
             v_local = sharded_forward(e, plan, self._frame_group(plan), x_local, t_local, exchange=getattr(e, "exchange", None))
+        if not gather:
+            if plan.cfg_groups == 1:
+                return v_local
+            self._gather_cfg_out = gather_cfg(v_local, plan, self._cfg_peer_group(plan), out=getattr(self, "_gather_cfg_out", None))
+            return self._gather_cfg_out
         self._gather_out = gather_frames(v_local, plan, self.process_group, out=getattr(self, "_gather_out", None))
         return self._gather_out[1]
+
+    def frame_slice(self, T: int, B: int = 1) -> slice:
+        """The frames forward_host_time(gather=False) covers on this rank."""
+        return self._plan(T, B).frame_slice
+
+    def gather_latent_frames(self, latents: torch.Tensor, B: int = 1) -> torch.Tensor:
+        """latents (T, ...) with this rank's frames current -> all frames current on every rank (in place, one all-gather over
+        the frame group): what a sampler that kept its latents sharded calls once, after the last step."""
+        plan = self._plan(latents.shape[0], B)
+        if plan.world > 1 and plan.frame_world > 1:
+            gather_latent_frames(latents, plan, self._frame_group(plan))
+        return latents
 
     def check_exchange(self, block: bool = True) -> None:
         """Raise if a flag wait of the copy-engine exchange gave up (a peer died or fell > 20 s behind: the attention then read

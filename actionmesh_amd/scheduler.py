@@ -9,6 +9,7 @@ window; each step is one C-ABI forward plus one fused CFG+Euler kernel.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
@@ -82,6 +83,10 @@ class HipSchedulerFlow:
     # branch's cross-attention is its to_out bias (zero context, bias-free to_k / to_v), and layer 0's self-attention branch is
     # computed once for all guidance branches (they carry the same latents and times until the first cross-attention).
     exact_shortcuts: bool = True
+    # Not a reference field.  Only matters with a denoiser that has a process group: `denoise` keeps the latents sharded by frames
+    # across the steps and gathers them once at the end; False = gather the velocity on every rank in every step
+    # (what the `_flow_sample` generator does when driven directly, where every yielded tensor has to be complete).
+    keep_latents_sharded: bool = True
 
     def get_schedule(self):
         """scheduler.py:43-56."""
@@ -112,8 +117,18 @@ class HipSchedulerFlow:
 
     def _flow_sample(self, diffusion_model, cf_guidance, init_latent, context, device="cuda:0",
                      disable_prog: bool = True, mask=None, framestep=None):
-        """scheduler.py:172-250 on the HIP path.  Yields (latents, t) like the reference (the same
-        tensor object every step; clone to record)."""
+        """scheduler.py:172-250 on the HIP path (the reference's signature).  Yields (latents, t) like the reference (the same
+        tensor object every step, complete on every rank; clone to record)."""
+        return self._flow_sample_impl(diffusion_model, cf_guidance, init_latent, context, device, disable_prog, mask, framestep)
+
+    def _flow_sample_impl(self, diffusion_model, cf_guidance, init_latent, context, device="cuda:0",
+                          disable_prog: bool = True, mask=None, framestep=None, local_latents: bool = False):
+        """`_flow_sample` plus one switch.
+        `local_latents` (a denoiser with a process group; what `denoise` uses): the latents stay SHARDED across the steps - every
+        rank advances only the frames it computes the velocity of (`forward_host_time(gather=False)`: no velocity collective at
+        all when the CFG batch sits on one group, one small all-gather among the same-frame ranks otherwise), and the frames are
+        gathered ONCE, behind the last step.  The tensor yielded before the last step then holds current values
+        only in this rank's frames."""
         if not isinstance(diffusion_model, HipDenoiser):
             raise TypeError("HipSchedulerFlow drives a HipDenoiser; got "
                             f"{type(diffusion_model).__name__} (there is no torch fallback path)")
@@ -140,6 +155,9 @@ class HipSchedulerFlow:
                 for g in branches]
 
         timesteps, distances = self.get_schedule()
+        local_latents = local_latents and diffusion_model.process_group is not None
+        fsl = diffusion_model.frame_slice(T, 1 if (self.split_cfg_batch and nb > 1) else nb) if local_latents else slice(0, T)
+        unobs_step = unobserved if unobserved is None else unobserved[fsl]
         split = self.split_cfg_batch and nb > 1
         zero = [self.exact_shortcuts and g[0] != 1 for g in branches]
         shared = self.exact_shortcuts and nb > 1 and all(k == keep[0] for k in keep)
@@ -157,22 +175,25 @@ class HipSchedulerFlow:
                 dt = float(torch.tensor(dt, dtype=torch.float32).to(h16))
             # every launch of the step goes to the denoiser's device and that device's current stream, whichever device is
             # current in the calling thread (the forward and the CFG+Euler kernel must share a stream to be ordered)
-            with torch.cuda.device(dev):
+            with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):   # (a CPU device: the gloo tests' stand-in engine)
                 if split:
                     # scheduler.py:159-168: branch by branch, each with its own slice of the context (the window is re-bound
                     # per branch: the K/V cache holds one context at a time, as the reference recomputes K/V every call)
                     vs = []
                     for b in range(nb):
                         diffusion_model.bind_window(ctx_b[b:b + 1], fs_b[b:b + 1], N, ctx_zero=zero[b:b + 1])
-                        vb = diffusion_model.forward_host_time(latents, [t * k for k in keep[b]])
+                        vb = diffusion_model.forward_host_time(latents, [t * k for k in keep[b]], gather=not local_latents)
                         # a sharded denoiser hands out its (re-used) gather buffer: keep a copy before the next branch overwrites it
                         vs.append(vb.clone() if diffusion_model.process_group is not None else vb)
                     v = torch.cat(vs, dim=0)
                 else:
                     t_bt = [t * k for row in keep for k in row]              # temporal_denoiser.py:209-212
                     x_in = latents.expand(nb, T, N, D).contiguous()
-                    v = diffusion_model.forward_host_time(x_in, t_bt)
-                ops.flow_step(v, latents[0], scales, dt, self.is_additive, unobserved)
+                    v = diffusion_model.forward_host_time(x_in, t_bt, gather=not local_latents)
+                # (T, N, D) fp32 is contiguous, so a frame range of it is too: the CFG + Euler kernel runs on this rank's frames only
+                ops.flow_step(v, latents[0][fsl], scales, dt, self.is_additive, unobs_step)
+                if local_latents and i == self.num_inference_steps - 1:
+                    diffusion_model.gather_latent_frames(latents[0], 1 if split else nb)
             diffusion_model.check_exchange(block=False)      # copy-engine exchange: last step's fault word, no device sync
             yield latents, timesteps[i]
 
@@ -183,8 +204,9 @@ class HipSchedulerFlow:
         """scheduler.py:252-295."""
         latents = None
         total = self.num_inference_steps
-        for step_idx, (sample, _t) in enumerate(self._flow_sample(
-                diffusion_model, cf_guidance, init_latent, context, device, disable_prog, mask, framestep)):
+        for step_idx, (sample, _t) in enumerate(self._flow_sample_impl(
+                diffusion_model, cf_guidance, init_latent, context, device, disable_prog, mask, framestep,
+                local_latents=self.keep_latents_sharded)):
             latents = sample
             if step_callback is not None:
                 step_callback(step_idx + 1, total)

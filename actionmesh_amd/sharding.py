@@ -91,6 +91,10 @@ class FrameShardPlan:
     def frame_group_ranks(self, cfg_rank: int) -> List[int]:
         return [cfg_rank * self.group_size + r for r in range(self.group_size)]
 
+    def cfg_peer_ranks(self, pos: int) -> List[int]:
+        """The ranks at position `pos` of every CFG group: same frame shard, the other guidance branches."""
+        return [g * self.group_size + pos for g in range(self.cfg_groups)]
+
     def slice_frames(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
         """Local frames of a (B, T, ...) tensor (contiguous copy); the batch is left alone."""
         idx = [slice(None)] * x.dim()
@@ -321,14 +325,49 @@ def gather_frames(v_local: torch.Tensor, plan: FrameShardPlan, group: Optional[d
     shape = (plan.world,) + tuple(v_local.shape)
     buf = out[0] if (out is not None and out[0].shape == shape and out[0].dtype == v_local.dtype and out[0].device == v_local.device) \
         else torch.empty(shape, dtype=v_local.dtype, device=v_local.device)
-    if v_local.is_cuda and dist.get_backend(group) == "gloo":
-        host = torch.empty(shape, dtype=v_local.dtype)
-        dist.all_gather_into_tensor(host.view(-1), v_local.cpu().view(-1), group=group)
-        buf.copy_(host)
-    else:
-        dist.all_gather_into_tensor(buf.view(-1), v_local.view(-1), group=group)
+    _all_gather_flat(buf, v_local, group)
     gs, fw, bl, tl = plan.group_size, plan.frame_world, plan.batch_local, plan.frames_local
     rest = tuple(v_local.shape[2:])
     g = buf.view((plan.cfg_groups, gs, bl, tl) + rest)[:, :fw]      # replicated groups: the first rank's copy stands for the group
     v = g.permute(0, 2, 1, 3, *range(4, 4 + len(rest))).reshape((plan.cfg_groups * bl, fw * tl) + rest)
     return buf, v
+
+
+def _all_gather_flat(buf: torch.Tensor, src: torch.Tensor, group) -> None:
+    """all_gather_into_tensor on flat views; a gloo group with device tensors is staged through the host (CPU tests, bench.py
+    --same-device: gloo's all-gather takes CPU tensors on every build)."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(buf.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host.view(-1), src.cpu().reshape(-1), group=group)
+        buf.copy_(host)
+    else:
+        dist.all_gather_into_tensor(buf.view(-1), src.reshape(-1), group=group)
+
+
+def gather_cfg(v_local: torch.Tensor, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B_local, T_local, ...) on the ranks that hold the same frames of different CFG branches (`group` = FrameShardPlan.
+    cfg_peer_ranks) -> (B, T_local, ...) on each of them: CFG group g holds batch block g, so the gathered buffer IS the batch in
+    order - one collective into a buffer that is allocated once (`out` = what this function returned last time)."""
+    if plan.cfg_groups == 1:
+        return v_local
+    v_local = v_local.contiguous()
+    shape = (plan.cfg_groups * v_local.shape[0],) + tuple(v_local.shape[1:])
+    buf = out if (out is not None and out.shape == shape and out.dtype == v_local.dtype and out.device == v_local.device) \
+        else torch.empty(shape, dtype=v_local.dtype, device=v_local.device)
+    _all_gather_flat(buf, v_local, group)
+    return buf
+
+
+def gather_latent_frames(latents: torch.Tensor, plan: FrameShardPlan, group: Optional[dist.ProcessGroup]) -> torch.Tensor:
+    """latents (T, ...) contiguous, frames plan.frame_slice current on this rank -> every frame current on every rank of the frame
+    group, in place: frame shard r IS row r of the (frame_world, T_local, ...) view, so the input aliases its slot of the output."""
+    if plan.frame_world == 1:
+        return latents
+    assert latents.is_contiguous() and latents.shape[0] == plan.n_frames
+    view = latents.view((plan.frame_world, plan.frames_local) + tuple(latents.shape[1:]))
+    if latents.is_cuda and dist.get_backend(group) == "gloo":
+        _all_gather_flat(view, view[plan.frame_rank].clone(), group)
+    else:
+        dist.all_gather_into_tensor(view.view(-1), view[plan.frame_rank].reshape(-1), group=group)
+    return latents

@@ -458,6 +458,8 @@ def main():
                          "device).  Executes every line of the world > 1 branch - groups, the sharded HipDenoiser, barriers, the MAX "
                          "all-reduce of the timing, the JSON - so that a first run on an 8-GPU node cannot fail on a typo; the numbers "
                          "are NOT a multi-GPU measurement and the line says so (tests/test_multi_gpu.py)")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N > 1: all-gather the velocity on every rank in every step (the round-3 sampler) instead of keeping the latents sharded")
     ap.add_argument("--cpu-baseline-deep", action="store_true",
                     help="cpu_baseline: add the N = 2048 sample (TL = 32 784; minutes of host time) so the fit is evaluated x2 instead of "
                          "x4 beyond its largest sample.  Off by default: the default run has to finish within a few minutes")
@@ -531,8 +533,11 @@ def main():
             barrier()
             torch.cuda.synchronize(dev)
 
-    loop = sched._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
-                              framestep=framestep)
+    # N > 1: the sampler keeps the latents sharded by frames across the steps, as HipSchedulerFlow.denoise does (no velocity gather
+    # per step; --gather-every-step restores it for A/B); the frames are gathered once, outside the timed region, for the fingerprint
+    local_latents = world > 1 and not args.gather_every_step
+    loop = sched._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
+                                   framestep=framestep, local_latents=local_latents)
     for _ in range(args.warmup):
         next(loop)
     sync()
@@ -544,6 +549,8 @@ def main():
     if world > 1:
         elapsed = max_over_ranks(elapsed)
     model.check_exchange(block=True)
+    if local_latents:
+        model.gather_latent_frames(init_latent[0], 2)
     assert bool(torch.isfinite(init_latent).all()), "non-finite latents"
     # what the sampler has made of the latents after warmup + steps steps: every rank holds the full tensor (like the reference), so a
     # 1-rank and an N-rank run of the same command must agree to the sharding tolerance (tests/test_multi_gpu.py compares them)
@@ -551,7 +558,8 @@ def main():
     fingerprint = {"after_steps": total, "rms": float(fp_lat.pow(2).mean().sqrt()), "mean": float(fp_lat.mean()),
                    "sample": [round(float(x), 6) for x in init_latent[0, -1, ::max(1, N // 8), 0].double().cpu()[:8]]}
     sched2 = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=True)
-    loop2 = sched2._flow_sample(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev), framestep=framestep)
+    loop2 = sched2._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev), framestep=framestep,
+                                     local_latents=local_latents)
     next(loop2)
     sync()
     t0 = time.perf_counter()
@@ -597,6 +605,7 @@ def main():
                                          "test_exact_shortcuts_are_bit_identical); `value` above executes every operation"},
         "hip_graph": bool(args.graph and world == 1),
         "latents_fingerprint": fingerprint,
+        "latents_sharded_across_steps": bool(local_latents),
         "end_to_end_video_to_4d_s": None,
         "end_to_end_note": "unmeasured: pretrained weights / assets unreachable offline; the GPU stages chained on synthetic "
                            "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",

@@ -287,3 +287,88 @@ def test_hipdenoiser_multirank_plumbing(world):
     x, ctx, fs, mask, t = _inputs()
     ref = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask, "fp32")
     assert torch.allclose(v, ref, rtol=1e-4, atol=2e-5), float((v - ref).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# The sampler with its latents kept SHARDED across the steps (HipSchedulerFlow.keep_latents_sharded):
+# every rank advances its own frames, no velocity gather per step (one small all-gather among the same-frame ranks when the
+# CFG branches are split over groups), frames gathered once behind the last step.  The CFG + Euler kernel (ops.flow_step) is a
+# HIP kernel; on CPU it is stood in for by the same arithmetic in torch - test infrastructure, like FakeHipEngine.
+# ---------------------------------------------------------------------------------------------
+def _flow_step_torch(v, latents, scales, dt, is_additive, unobserved):
+    r = lambda x: x.to(torch.bfloat16).float()
+    vb = [r(v[b].float()) for b in range(v.shape[0])]
+    out, prev = vb[0], vb[0]
+    for b in range(1, len(vb)):
+        out = r(out + r(float(scales[b - 1]) * r(vb[b] - prev)))
+        prev = vb[b]
+    upd = (1.0 if is_additive else -1.0) * r(dt * out)
+    for f in range(latents.shape[0]):
+        if unobserved is None or unobserved[f]:
+            latents[f] += upd[f]
+
+
+def _sampler_worker(rank, world, port, q, cfg_parallel, split):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import actionmesh_amd.denoiser as D
+        import actionmesh_amd.scheduler as S
+        torch.set_num_threads(2)
+        D.HipEngine = FakeHipEngine
+        S.ops.flow_step = _flow_step_torch
+        calls = {"all": 0}
+        orig = dist.all_gather_into_tensor
+
+        def counting(out, inp, *a, **k):
+            calls["all"] += 1
+            calls["bytes"] = calls.get("bytes", 0) + out.numel() * out.element_size()
+            return orig(out, inp, *a, **k)
+        dist.all_gather_into_tensor = counting
+        cfg = O.OracleConfig(**KW)
+        sd = O.synthetic_state_dict(cfg, seed=0)
+        x, ctx, fs, mask, _t = _inputs()
+        outs, ncoll = [], []
+        for keep in (True, False):
+            model = D.HipDenoiser(num_tokens_nominal=20, temporal_context_size=4, process_group=dist.group.WORLD,
+                                  cfg_parallel=cfg_parallel, **KW)
+            model.load_state_dict(sd)
+            sched = S.HipSchedulerFlow(num_inference_steps=3, shift=3.0, is_additive=True, split_cfg_batch=split,
+                                       keep_latents_sharded=keep, exact_shortcuts=False)
+            cfgd = S.ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+            calls["all"], calls["bytes"] = 0, 0
+            lat = sched.denoise(model, cfgd, x[:1].clone(), ctx[1:2], device="cpu", mask=mask[:1], framestep=fs[:1])
+            outs.append(lat.clone())
+            ncoll.append((calls["all"], calls["bytes"]))
+        q.put((rank, outs[0], outs[1], ncoll))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,cfg_parallel,split", [(2, False, False), (2, True, False), (4, True, False), (2, False, True)])
+def test_sampler_keeps_latents_sharded_across_steps(world, cfg_parallel, split):
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29400 + (os.getpid() * 5 + world * 19 + 3 * cfg_parallel + 7 * split) % 500
+    procs = [ctxm.Process(target=_sampler_worker, args=(r, world, port, q, cfg_parallel, split)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = got[0][2]
+    for rank, sharded, gathered, ncoll in got:
+        assert torch.equal(gathered, ref), f"rank {rank}: gather-every-step latents differ between ranks"
+        assert torch.equal(sharded, gathered), f"rank {rank}: sharded-latents sampler differs from the gather-every-step one"
+        (n_sh, b_sh), (n_ga, b_ga) = ncoll
+        assert n_sh <= n_ga + 1 and b_sh <= b_ga, (rank, ncoll)      # (+1: the one frame gather behind the last step)
+        if world > 2 or not cfg_parallel:                # frames are sharded: strictly fewer gathered bytes
+            assert b_sh < b_ga, (rank, ncoll)
+    if not cfg_parallel:          # one CFG group: the only velocity-side collective left is the final frame gather
+        steps, layers_inflated = 3, sum(1 for i in range(KW["num_layers"]) if i in KW["inflated_layers"])
+        per_forward_kv = 2 * layers_inflated                     # K and V^T shards, one all-gather each per inflated layer
+        forwards = steps * (2 if split else 1)
+        assert got[0][3][0][0] == forwards * per_forward_kv + 1, got[0][3]

@@ -665,15 +665,11 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
       // Measured same-box, warm (profiles/r03h_gemm_skew.txt, "off" vs best): qkv 0.828 -> 0.756 ms, ff1+GELU 1.262 -> 1.164, ff2 0.951 -> 0.936;
       // nominal qkv 1.369 -> 1.302.
     const int units = (p.act >> 13) & 7;
-    // EXPERIMENT (round 4, VERDICT r03 next #3 "split-tile schedule"): a second, SMALL skew inside an XCD - workgroup idx of an XCD
-    // starts ((idx & 3) * sub) x 0.1 us late, sub from ACTIONMESH_AMD_GEMM_SUBSKEW through the upper bits of m_base - so that the
-    // epilogues of an XCD's 32 workgroups do not land together while the workgroups stay within a few k-tiles of each other (L2).
-    const int sub = m_base >> 20;
-    m_base &= 0xfffff;
-    if (((units && units < 7) || sub) && bid < 256) {
+    // (an additional INTRA-XCD skew - the XCD's workgroups entering their epilogues at four different times - was measured in round 4
+    // and dropped: no gain at 0.5-2 us, 1.5-4 % slower at 4-8 us; tools/experiments/gemm_subskew.patch, profiles/r04m_gemm_subskew.txt)
+    if (units && units < 7 && bid < 256) {
       const unsigned long long t0 = wall_clock64();
-      const unsigned long long wait = (unsigned long long)(bid & 7) * ((units && units < 7) ? units : 0) * 150ull      // 100 MHz clock
-                                      + (unsigned long long)((bid >> 3) & 3) * sub * 10ull;
+      const unsigned long long wait = (unsigned long long)(bid & 7) * units * 150ull;      // 100 MHz clock
       while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -907,11 +903,6 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_bf16_kernel(am_gemm_args p, 
 // partition mode: an MI355X (gfx950) in SPX mode - 256 CUs visible as one device.  Anywhere else (CPX / DPX partitions, CU-masked
 // streams shrink multiProcessorCount; other parts) the skew would be pure added latency, so it is 0 there; the environment
 // variable ACTIONMESH_AMD_GEMM_SKEW=0 turns it off on the MI355X as well.
-static int gemm_subskew() {            // experiment knob: intra-XCD start skew in 0.1 us steps (default 0 = off)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ACTIONMESH_AMD_GEMM_SUBSKEW"); v = e ? atoi(e) : 0; if (v < 0 || v > 2000) v = 0; }
-  return v;
-}
 static int gemm_skew_units(int rounds) {
   static int enabled[64];           // 0 unknown, 1 on, 2 off
   int dev = 0;
@@ -1006,7 +997,7 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
         if (part_done > m_main) part_done = m_main;
       }
       hipLaunchKernelGGL(gemm256pp_bf16_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES,
-                         (hipStream_t)stream, main_args, tiles_m, tiles_n, gemm_subskew() << 20, am_headpost_args{});
+                         (hipStream_t)stream, main_args, tiles_m, tiles_n, 0, am_headpost_args{});
     }
     if (m_main < args.M) {
       const int tn = ceil_div(args.N, BN);
@@ -1067,7 +1058,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   am_gemm_args main_args = args;
   main_args.M = m_main;                      // the fused epilogue bounds its rows by M: the main grid owns [0, m_main)
   hipLaunchKernelGGL(gemm256pp_bf16_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES, (hipStream_t)stream, main_args, tiles_m,
-                     tiles_n, gemm_subskew() << 20, *hp);
+                     tiles_n, 0, *hp);
   if (m_main < args.M) {                     // the remainder rows: plain linear into X, then the head split of exactly those rows
     const int tn = ceil_div(args.N, BN);
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);

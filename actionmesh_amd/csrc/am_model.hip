@@ -397,11 +397,7 @@ extern "C" int am_load_weight(am_handle h, const char* name, const float* host, 
     AM_HIP(hipMemcpy(s.dst, tmp.data(), numel * sizeof(float), hipMemcpyHostToDevice));
   }
   h->loaded.insert(name);
-  h->folds_ready = false;
-  if (h->ln_fold && am_weights_missing(h) == 0) {      // the last key of a state dict: fold the norms into their linears once
-    AM_TRY(prepare_folds(h, nullptr));
-    AM_HIP(hipStreamSynchronize(nullptr));
-  }
+  h->folds_ready = false;         // the folded linears (am_layer.wf_*) are rebuilt by the next forward's entry point, never inside a capture
   return AM_OK;
 }
 
@@ -521,6 +517,7 @@ extern "C" int am_forward_begin(am_handle h, const float* x_dev, const float* t_
   AM_TRY(forward_check(h, x_dev, t_bt_host, B, T, N));
   AM_TRY(ensure_kv(h));
   hipStream_t st = (hipStream_t)stream;
+  if (h->ln_fold && !h->folds_ready) AM_TRY(prepare_folds(h, st));     // weights were (re)loaded since the last forward
   AM_TRY(stage_h2d(h, h->tdev, t_bt_host, (size_t)B * T * sizeof(float), st));
   return forward_begin_body(h, x_dev, B, T, N, st);
 }
@@ -539,10 +536,7 @@ static int forward_begin_body(am_model* h, const float* x_dev, int B, int T, int
   AM_TRY(gemm(st, h->te1, 4 * C, h->w_t2, 4 * C, h->b_t2, nullptr, h->hwork, C, BT, C, 4 * C, 0, nullptr, 0, 0, 0, 0, 0,
               /*cG*/ 1, /*cgs*/ h->L, /*coff*/ 0));
   TR(23, 0, h->hwork, (size_t)h->R * C * 2);
-  if (h->ln_fold) {
-    if (!h->folds_ready) AM_TRY(prepare_folds(h, st));      // a handle run with part of its state dict (tests): fold what is there
-    AM_TRY(am_row_stats_bf16(h->hwork, h->ln_stats, h->R, C, 1e-5f, st));
-  }
+  if (h->ln_fold) AM_TRY(am_row_stats_bf16(h->hwork, h->ln_stats, h->R, C, 1e-5f, st));
   h->hsrc = h->hwork;
   h->skip_top = 0;
   h->next_layer = 0;
@@ -908,6 +902,7 @@ extern "C" int am_denoise_forward_graph(am_handle h, const float* x_dev, const f
     return am_denoise_forward(h, x_dev, t_bt_host, B, T, N, v_out, stream);
   }
   AM_TRY(forward_check(h, x_dev, t_bt_host, B, T, N));
+  if (h->ln_fold && !h->folds_ready) AM_TRY(prepare_folds(h, st));     // in front of a replay or a capture, never inside one
   const bool same = g.x == x_dev && g.v == v_out && g.B == B && g.T == T && g.N == N && g.st == st && g.ctx_gen == h->ctx_gen &&
                     g.scratch_gen == g_am_scratch_generation.load();
   if (!same) {

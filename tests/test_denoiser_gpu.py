@@ -525,6 +525,51 @@ def test_folded_layernorms(dev, golden_dir, name, monkeypatch):
     assert rel(v, ref32) < 1.05 * rel(v0, ref32)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_reloaded_weights_rebuild_the_folded_linears(dev, golden_dir, use_graph):
+    """am_load_weight on a live handle (a C-ABI user swapping a LayerNorm's affine or the linear behind it): the folded linears are
+    rebuilt by the next forward's entry point - in front of a graph replay too - and the result is the one of a fresh handle."""
+    import ctypes as C
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser
+    name = "tiny_mixed"
+    g, cfg, sd, model, t = _setup(name, golden_dir, dev)
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+    x_in, c_in, m_in, f_in = cfgd.cfg_at_inference(t["init_latent"], t["context"], t["mask"], t["framestep"])
+    tt = torch.tensor([float(g["fwd_t"])]).expand(2)
+
+    def build(state):
+        m = HipDenoiser(num_tokens_nominal=48, temporal_context_size=4, use_graph=use_graph, **CASES[name])
+        m.load_state_dict(state)
+        return m.to(dev).eval()
+
+    def fwd(m, n=1):
+        cache, v = None, None
+        for _ in range(n):                       # graph engines: eager, captured, replayed
+            v, cache = m.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), cache)
+        torch.cuda.synchronize()
+        return v.float().cpu(), cache
+
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    changed = ("blocks.1.norm_ff.weight", "blocks.0.norm_s_attn.bias", "blocks.2.norm_x_attn.weight", "blocks.3.ff.net.0.proj.weight",
+               "blocks.3.ff.net.0.proj.bias", "blocks.4.s_attn.to_k.weight")
+    gen = torch.Generator().manual_seed(3)
+    for k in changed:
+        sd2[k] = sd2[k] * (1.0 + 0.3 * torch.randn(sd2[k].shape, generator=gen)) + 0.05
+    m = build(sd)
+    v_old, cache = fwd(m, 3)
+    e = m._engine
+    for k in changed:
+        w = sd2[k].detach().to("cpu", torch.float32).contiguous()
+        e._check(e.lib.am_load_weight(e.handle, k.encode(), C.c_void_p(w.data_ptr()), w.numel()), f"am_load_weight({k})")
+    v_new = None
+    for _ in range(2):
+        v_new, cache = m.forward(x_in.to(dev), c_in.to(dev), f_in.to(dev), tt.to(dev), m_in.to(dev), cache)
+    torch.cuda.synchronize()
+    want, _ = fwd(build(sd2), 3)
+    assert not torch.equal(v_old, want)
+    assert torch.equal(v_new.float().cpu(), want)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_graph_replay_is_bit_identical(dev, golden_dir, name):
     """am_denoise_forward_graph (HipDenoiser(use_graph=True)): the sampler through a captured forward - first step eager, second

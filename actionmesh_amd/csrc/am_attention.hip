@@ -633,14 +633,19 @@ int launch(const am_attn_args* a, void* stream) {
   constexpr bool BALANCED = MAIN == 1;
   const bool use64 = MAIN == 2 || (MAIN == 3 && ceil_div(a->sk, KVBLK) * a->nchunks >= 16);
   using G = Geo<NW, NSUB>;
+  // The split tail (a short last query block cut SPLIT_Z ways over the key range) always runs the 4-wave / 128-row geometry: at most
+  // G::QBLK / 2 <= 128 rows are valid, so one 128-row block holds them, half as many waves walk keys for padding rows, and two
+  // workgroups share a CU (round 4; profiles/r04z_split_tail.txt - before, it ran in the caller's 256-row geometry: 143 + 9 us).
+  using GS = Geo<4, 1>;
+  constexpr int RATIO = G::QBLK / GS::QBLK;
   AM_ONCE_PER_DEVICE({
     if (BALANCED)
       AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_balanced_kernel<DEFER>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUB_B));
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, false, NW, NSUB>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
-    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true, NW, NSUB>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DEFER, true, 4, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GS::SMEM));
   });
   const int tiles_per_chunk = ceil_div(a->sk, KVBLK);
   const int all_supers = ceil_div(tiles_per_chunk, NSUB) * a->nchunks;
@@ -650,12 +655,15 @@ int launch(const am_attn_args* a, void* stream) {
   // split the short last query block over the key range when it would otherwise add a round
   static float* part = nullptr;       // library-owned scratch, grown on demand
   static size_t part_elems = 0;
-  const size_t need = (size_t)bh * SPLIT_Z * G::QBLK * PART_LD;
+  // (32 cuts instead of 16 change nothing - measured: the pass re-reads every K / V^T byte of the launch for 16 query rows, 537 MB at the
+  // headline shape = 107 us at 5 TB/s, and sits at 116 us: it is at its HBM floor)
+  const int Z = SPLIT_Z;
+  const size_t need = (size_t)bh * Z * GS::QBLK * PART_LD;
   // a->rows: 0 = every query block; 1 = only the blocks the 4x64 kernel takes ("main": all but a short last block);
   // 2 = only what rows = 1 leaves out.  The main/rest boundary depends on the query geometry alone, so the calls of a
   // two-pass sequence (different nchunks) agree on it.
   const bool tail_geom = nblk >= 9 && tail_rows <= G::QBLK / 2;
-  const bool can_split = all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
+  const bool can_split = (int64_t)tiles_per_chunk * a->nchunks >= 2 * SPLIT_Z && all_supers >= 2 * SPLIT_Z && need * sizeof(float) <= (256u << 20);
   const bool split = tail_geom && can_split;
   if (a->rows == 1) {
     AM_CHECK(use64, "am_attention_bf16: rows = 1 / two-pass needs the 4x64 kernel (>= 16 key tiles in the chunks walked)");
@@ -685,10 +693,10 @@ int launch(const am_attn_args* a, void* stream) {
     hipLaunchKernelGGL((attn_fwd_kernel<DEFER, false, NW, NSUB>), dim3(split ? nblk - 1 : nblk, bh), dim3(G::THREADS), G::SMEM,
                        st, *a, tiles_per_chunk, 0, (float*)nullptr);
   if (split) {
-    hipLaunchKernelGGL((attn_fwd_kernel<DEFER, true, NW, NSUB>), dim3(1, bh, SPLIT_Z), dim3(G::THREADS), G::SMEM, st, *a,
-                       tiles_per_chunk, nblk - 1, part);
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(tail_rows, bh), dim3(128), 0, st, *a, part, SPLIT_Z, nblk - 1, tail_rows,
-                       G::QBLK);
+    hipLaunchKernelGGL((attn_fwd_kernel<DEFER, true, 4, 1>), dim3(1, bh, Z), dim3(GS::THREADS), GS::SMEM, st, *a,
+                       tiles_per_chunk, (nblk - 1) * RATIO, part);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(tail_rows, bh), dim3(128), 0, st, *a, part, Z, (nblk - 1) * RATIO, tail_rows,
+                       GS::QBLK);
   }
   AM_HIP(hipGetLastError());
   return AM_OK;
@@ -730,9 +738,14 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
            "am_attention_bf16: chunk_first/chunk_total need rows = 1, 0 <= first < total, nchunks <= total");
   AM_CHECK(a->rows != 1 || a->defer_log2 == 0 || a->defer_log2 == 8 || a->defer_log2 == 60 || a->defer_log2 == 68 || a->defer_log2 == 28,
            "am_attention_bf16: rows = 1 runs on the product dispatch only");
+  // Short key streams (< 16 tiles: the cross-attention's 257 context tokens, the encoders' sequences) run the 8-wave kernel's
+  // code in its OTHER geometry - two independent 4-wave workgroups per CU, 64 KiB of LDS each: a workgroup that walks 5 key tiles is
+  // mostly prologue (Q fragments, the first K / V^T tiles in flight) and epilogue, and the second resident workgroup covers them.
+  // Same arithmetic per row: bit-identical output; 15-18 % faster at the cross shapes (profiles/r04y_cross_attn_geometry.txt).
+  const bool short_stream = a->rows == 0 && (int64_t)ceil_div(a->sk, KVBLK) * a->nchunks < 16;
   switch (a->defer_log2) {
-    case 0: return launch<0, 8, 2, 3>(a, stream);
-    case 8: return launch<8, 8, 2, 3>(a, stream);
+    case 0: return short_stream ? launch<0, 4, 1>(a, stream) : launch<0, 8, 2, 3>(a, stream);
+    case 8: return short_stream ? launch<8, 4, 1>(a, stream) : launch<8, 8, 2, 3>(a, stream);
     case 90: return launch<0, 8, 2>(a, stream);      // forced 8-wave kernel (A/B, tests)
     case 98: return launch<8, 8, 2>(a, stream);
     case 50: return launch<0, 4, 1>(a, stream);     // geometry A/B: two 4-wave workgroups per CU

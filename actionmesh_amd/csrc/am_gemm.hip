@@ -206,6 +206,88 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The remainder rows of a big GEMM (M = B T (N + 1) is 256 k + 32 at every reference shape: the one time token per frame), round 4.
+// They used to go to the 128x128 kernel above: N / 128 workgroups, each walking ALL of K one 64-column tile at a time with ONE tile
+// in flight - a chain of K / 64 exposed global-load latencies on a grid of 8-32 workgroups, 20-60 us per launch, six launches per
+// layer (0.6 % of the step for 0.02 % of the flops).  This kernel is built for latency instead: a workgroup owns 32 rows x 64
+// columns, its 8 waves are 2 column blocks x 4 K-QUARTERS, fragments come straight from global memory in MFMA layout (a lane's 8
+// consecutive k of its row: one 16-byte load, no LDS staging), eight k-steps of loads are in flight per wave before their MFMAs, and
+// the four K-quarters are summed through LDS.  Identity row maps only (am_gemm_bf16 keeps the 128x128 kernel for the rest).
+// Epilogue arithmetic = the other kernels' (bias, folded LayerNorm, GELU, residual, the same rounding points).
+constexpr int TAIL_LD = 64 + 4;       // fp32 per staged row
+__global__ __launch_bounds__(512) void gemm_tail_kernel(am_gemm_args p, int m_base) {
+  __shared__ float red[4][32][TAIL_LD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int m0 = m_base + blockIdx.y * 32, nb0 = blockIdx.x * 64;
+  const int ar = min(m0 + l31, p.M - 1);
+  const int wr = min(nb0 + wn * 32 + l31, p.N - 1);
+  const bf16_t* a1 = p.A1 + (int64_t)ar * p.lda1 + hi * 8;
+  const bf16_t* a2 = p.A2 ? p.A2 + (int64_t)ar * p.lda2 + hi * 8 - p.K1 : nullptr;
+  const bf16_t* wp = p.W + (int64_t)wr * p.ldw + hi * 8;
+  const int kq = p.K >> 2;                       // K % 64 == 0: a quarter is a whole number of 16-element k-steps
+  const int k_begin = wk * kq, k_end = k_begin + kq;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = k_begin; k0 < k_end; k0 += 128) {
+    u32x4_t af[8], wf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = min(k0 + s * 16, k_end - 16);        // a short last group re-reads its last step; its MFMA is skipped below
+      af[s] = *reinterpret_cast<const u32x4_t*>((k < p.K1 ? a1 : a2) + k);
+      wf[s] = *reinterpret_cast<const u32x4_t*>(wp + k);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (k0 + s * 16 < k_end)
+        acc = AM_MFMA_32x32x16(__builtin_bit_cast(bf16x8_t, wf[s]), __builtin_bit_cast(bf16x8_t, af[s]), acc);
+  }
+  // D = W A^T: lane l31 = output row, register 4 g + e = column 8 g + 4 hi + e of the wave's 32
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4_t*>(&red[wk][l31][wn * 32 + 8 * g + 4 * hi]) = f32x4_t{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+  __syncthreads();
+  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int gmr = m0 + row, gn = nb0 + c4;
+  if (gmr >= p.M || gn >= p.N) return;
+  float v[4];
+  {
+    const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(&red[0][row][c4]), s1 = *reinterpret_cast<const f32x4_t*>(&red[1][row][c4]);
+    const f32x4_t s2 = *reinterpret_cast<const f32x4_t*>(&red[2][row][c4]), s3 = *reinterpret_cast<const f32x4_t*>(&red[3][row][c4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (s0[e] + s1[e]) + (s2[e] + s3[e]);
+  }
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + gn);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = b[e];
+  }
+  if (p.ln_stats) {
+    const f32x2_t st = *reinterpret_cast<const f32x2_t*>(p.ln_stats + 2 * (int64_t)gmr);
+    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.ln_colsum + gn);
+    const float nm = -st[0] * st[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rbf(fmaf(v[e], st[1], fmaf(nm, cs[e], bv[e])));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rbf(v[e] + bv[e]);
+  }
+  if ((p.act & 0xff) == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = rbf(gelu_erf(v[e]));
+  }
+  if (p.residual) {
+    const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(p.residual + (int64_t)gmr * p.ldc + gn);
+    v[0] += bflo(rv[0]); v[1] += bfhi(rv[0]); v[2] += bflo(rv[1]); v[3] += bfhi(rv[1]);
+  }
+  *reinterpret_cast<u32x2_t*>(p.C + (int64_t)gmr * p.ldc + gn) = u32x2_t{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+
 // Shared tail of the 256x256 kernels: the bf16 tile staged in LDS (row = 512 B, 8-byte unit u of row m at u ^ (m & 15))
 // goes out as row-contiguous 16-byte stores with the residual added on the way.
 #ifndef AM_GEMM_NT
@@ -921,6 +1003,20 @@ static int gemm_skew_units(int rounds) {
 // am_norm.hip: (mean, M2) of the 256-column slices of rows [row0, row0 + rows) of C, into part [row][ceil(N / 256)][2]
 int am_row_part(const bf16_t* Cmat, int ldc, int64_t row0, int64_t rows, int N, float* part, void* stream);
 
+// rows [m_main, M) of a big GEMM: the latency-built tail kernel when the row maps are the identity (every reference shape), the
+// 128x128 kernel otherwise (or with ACTIONMESH_AMD_GEMM_TAIL=128, for A/B)
+static void launch_tail(const am_gemm_args& args, int m_main, hipStream_t st) {
+  static int use128 = -1;
+  if (use128 < 0) { const char* e = getenv("ACTIONMESH_AMD_GEMM_TAIL"); use128 = (e && strcmp(e, "128") == 0) ? 1 : 0; }
+  const int rows = args.M - m_main;
+  if (!use128 && args.a_G == 0 && args.c_G == 0 && rows <= 128 && args.N % 4 == 0 && ((uintptr_t)args.bias % 16 == 0)) {
+    hipLaunchKernelGGL(gemm_tail_kernel, dim3(ceil_div(args.N, 64), ceil_div(rows, 32)), dim3(512), 0, st, args, m_main);
+  } else {
+    const int tn = ceil_div(args.N, BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, st, args, 1, tn, m_main);
+  }
+}
+
 extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
   AM_CHECK(a != nullptr, "am_gemm_bf16: null args");
   AM_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "am_gemm_bf16: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -999,10 +1095,7 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
       hipLaunchKernelGGL(gemm256pp_bf16_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES,
                          (hipStream_t)stream, main_args, tiles_m, tiles_n, 0, am_headpost_args{});
     }
-    if (m_main < args.M) {
-      const int tn = ceil_div(args.N, BN);
-      hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
-    }
+    if (m_main < args.M) launch_tail(args, m_main, (hipStream_t)stream);
   } else {
     const int tiles_m = ceil_div(args.M, BM), tiles_n = ceil_div(args.N, BN);
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), SMEM_BYTES,
@@ -1059,10 +1152,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
   main_args.M = m_main;                      // the fused epilogue bounds its rows by M: the main grid owns [0, m_main)
   hipLaunchKernelGGL(gemm256pp_bf16_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), SMEM2PP_BYTES, (hipStream_t)stream, main_args, tiles_m,
                      tiles_n, 0, *hp);
-  if (m_main < args.M) {                     // the remainder rows: plain linear into X, then the head split of exactly those rows
-    const int tn = ceil_div(args.N, BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(tn), dim3(256), SMEM_BYTES, (hipStream_t)stream, args, 1, tn, m_main);
-  }
+  if (m_main < args.M) launch_tail(args, m_main, (hipStream_t)stream);   // the remainder rows: plain linear into X, then the head split of exactly those rows
   AM_HIP(hipGetLastError());
   // tokens the fused epilogue did not produce: the tail rows (all in the last sequence) and the pad rows / columns of every sequence
   const int s_min_last = hp->seq_len - (args.M - m_main);

@@ -1,4 +1,4 @@
-"""`python -m actionmesh_amd.cli [--backend {hip,reference}] [--attn-dtype {bf16,fp8}] [--stage2-hip] [--script NAME]
+"""`python -m actionmesh_amd.cli [--backend {hip,reference}] [--attn-dtype {bf16,fp8,fp8_fast}] [--stage2-hip] [--script NAME]
                                  [--reference-root DIR] -- <the reference CLI's own arguments>`
 
 Runs the reference's UNMODIFIED command-line script (inference/video_to_animated_mesh.py:120-248, or
@@ -39,7 +39,8 @@ def split_args(argv: List[str]) -> Tuple[argparse.Namespace, List[str]]:
     ap = argparse.ArgumentParser(prog="python -m actionmesh_amd.cli", add_help=False,
                                  description="Run the reference ActionMesh CLI on the MI355X backend (or untouched).")
     ap.add_argument("--backend", choices=["hip", "reference"], default="hip")
-    ap.add_argument("--attn-dtype", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--attn-dtype", choices=["bf16", "fp8", "fp8_fast"], default="bf16",
+                    help="inflated self-attention arithmetic: bf16 (default), e4m3 MFMA (fp8), or its exponent-field form (fp8_fast)")
     ap.add_argument("--stage2-hip", action="store_true", help="also decode Stage II on the HIP kernels (HipAutoencoder)")
     ap.add_argument("--script", choices=SCRIPTS, default=SCRIPTS[0])
     ap.add_argument("--reference-root", default=None)

@@ -82,7 +82,19 @@ class AmAttnArgs(C.Structure):
     ]
 
 
-# every symbol include/actionmesh_amd.h declares: name -> (restype, argtypes)
+PEER_MAX_RANKS = 16
+
+
+class AmPeerRing(C.Structure):          # include/actionmesh_amd_sharded.h
+    _fields_ = [
+        ("world", C.c_int32), ("rank", C.c_int32), ("chunk_bytes", C.c_uint64),
+        ("kv", C.c_void_p), ("flags", C.c_void_p),
+        ("peer_kv", C.c_void_p * PEER_MAX_RANKS), ("peer_flags", C.c_void_p * PEER_MAX_RANKS),
+        ("side_stream", C.c_void_p), ("seq", C.c_uint32),
+    ]
+
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
     "am_last_error": (C.c_char_p, []),
@@ -138,6 +150,7 @@ SYMBOLS = {
     "am_f32_to_bf16": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "am_forward_sharded_peer": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(AmPeerRing), _P, C.c_int, _P]),
 }
 
 _libs = {}

@@ -223,6 +223,26 @@ class HipEngine:
             self._check(self.lib.am_forward_end(self.handle, v.data_ptr(), self._stream()), "am_forward_end")
         return v
 
+    def forward_peer(self, x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
+        """The frame-sharded forward of this rank over the copy-engine exchange (`self.exchange`, a sharding.PeerExchange) in ONE C
+        call: am_forward_sharded_peer (include/actionmesh_amd_sharded.h) - begin, per layer pre / push + local attention / wait / post /
+        consumed, end.  What sharding.sharded_forward(exchange=...) does from Python, launch for launch."""
+        ex = self.exchange
+        if ex is None or self.world <= 1:
+            raise RuntimeError("HipEngine.forward_peer: no copy-engine exchange is bound (world > 1 with a PeerExchange kv_factory)")
+        B, T, N, D = x_local.shape
+        x_local = x_local.to(self.device, torch.float32).contiguous()
+        t = (C.c_float * (B * T))(*t_bt_local)
+        v = torch.empty((B, T, N, D), dtype=self.h16, device=self.device)
+        infl = (C.c_uint8 * self.num_layers)(*[1 if self.is_inflated(i) else 0 for i in range(self.num_layers)])
+        ring = ex.ring()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.am_forward_sharded_peer(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(), C.byref(ring), infl,
+                                                         self.num_layers, self._stream()), "am_forward_sharded_peer")
+        ex.sync_seq()
+        self._x_keepalive = x_local
+        return v
+
     def forward(self, x_local: torch.Tensor, t_bt_local: List[float]) -> torch.Tensor:
         """Single-rank convenience: the whole forward in one C call."""
         B, T, N, D = x_local.shape

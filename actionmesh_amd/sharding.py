@@ -190,6 +190,24 @@ class PeerExchange:
     def kv_ptr(self) -> int:
         return self.kv.value
 
+    def ring(self):
+        """This rank's view of the exchange as the C struct of include/actionmesh_amd_sharded.h (am_forward_sharded_peer: the phase loop
+        in C).  The struct shares the sequence counter with this object: `sync_seq()` after a C-driven forward."""
+        if getattr(self, "_ring", None) is None:
+            r = self.L.AmPeerRing()
+            r.world, r.rank, r.chunk_bytes = self.P, self.me, self.chunk_bytes
+            r.kv, r.flags = self.kv.value, self.flags.value
+            for p in range(self.P):
+                if p != self.me:
+                    r.peer_kv[p], r.peer_flags[p] = self.peer_kv[p], self.peer_flags[p]
+            r.side_stream = self.side.cuda_stream
+            self._ring = r
+        self._ring.seq = self.seq
+        return self._ring
+
+    def sync_seq(self) -> None:
+        self.seq = int(self._ring.seq)
+
     def _arrived(self, base: int, src: int) -> int:
         return base + 4 * src
 
@@ -270,6 +288,12 @@ class PeerExchange:
         self.kv = None
 
 
+def phase_loop_in_c() -> bool:
+    """The copy-engine back-end's per-layer phase loop runs in C (am_forward_sharded_peer) unless ACTIONMESH_AMD_PHASE_LOOP=python
+    (the statement-for-statement Python original below, kept for the diagnostics that hook its steps)."""
+    return os.environ.get("ACTIONMESH_AMD_PHASE_LOOP", "c").lower() != "python"
+
+
 def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.ProcessGroup],
                     x_local: torch.Tensor, t_bt_local: List[float], exchange: Optional[PeerExchange] = None) -> torch.Tensor:
     """One denoiser forward over this rank's (batch rows, frames); returns the local velocity.
@@ -277,6 +301,12 @@ def sharded_forward(engine: Engine, plan: FrameShardPlan, group: Optional[dist.P
     Engines that offer `layer_attn_local` (HipEngine) overlap the exchange with the attention of the full query
     blocks against the local shard: softmax is order-free over keys, so the kernel saves (O, m, l) after the local
     keys and resumes over the remote ones once they have landed."""
+    if exchange is not None and plan.frame_world > 1 and hasattr(engine, "forward_peer") and phase_loop_in_c():
+        v = engine.forward_peer(x_local, t_bt_local)        # the loop below as ONE C call (am_forward_sharded_peer): same launches, same order
+        if exchange.faulted(block=False):
+            raise RuntimeError("sharded_forward: the copy-engine exchange timed out waiting for a peer's K/V shard; the result is invalid")
+        exchange.post_fault_word()
+        return v
     engine.begin(x_local, t_bt_local)
     attn_local = getattr(engine, "layer_attn_local", None)
     for i in range(engine.num_layers):

@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
 def test_library_loads_and_exports_every_declared_symbol(kind):
     """Both builds of the sources: libactionmesh_amd.so (bfloat16) and libactionmesh_amd_f16.so (-DAM_F16: `--dtype float16`)."""
-    header = open(os.path.join(ROOT, "include", "actionmesh_amd.h")).read()
+    inc = os.path.join(ROOT, "include")
+    header = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     declared = set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", header))
     declared -= {"am_status"}
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
@@ -32,8 +33,9 @@ def test_struct_layouts_match_header(tmp_path):
     """ctypes mirrors vs the C header, measured by compiling a probe with gcc against include/."""
     import subprocess
     structs = {"am_config": _lib.AmConfig, "am_gemm_args": _lib.AmGemmArgs,
-               "am_headpost_args": _lib.AmHeadPostArgs, "am_attn_args": _lib.AmAttnArgs, "am_nn_args": _lib.AmNnArgs}
-    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "actionmesh_amd.h"', 'int main(void){']
+               "am_headpost_args": _lib.AmHeadPostArgs, "am_attn_args": _lib.AmAttnArgs, "am_nn_args": _lib.AmNnArgs,
+               "am_peer_ring": _lib.AmPeerRing}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "actionmesh_amd.h"', '#include "actionmesh_amd_sharded.h"', 'int main(void){']
     for cname, cls in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _t in cls._fields_:

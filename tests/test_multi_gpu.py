@@ -61,6 +61,18 @@ def test_copy_engine_exchange_across_processes_on_one_device(world):
     print(out.strip().splitlines()[-2])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_phase_loop_in_c_equals_the_python_loop(dtype):
+    """the sharded forward's per-layer phase loop as ONE C call (am_forward_sharded_peer, include/actionmesh_amd_sharded.h:
+    begin, pre, pushes + local attention, wait, post, consumed, end) against sharding.sharded_forward's Python loop - two processes on
+    one device, four forwards alternating between the two drivers on the SAME exchange ring (the sequence flags keep turning
+    across them), outputs bit-identical on every rank, and the usual comparison against the unsharded forward."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = _run(2, ("--same-device", "--loop", "both", "--forwards", "4", "--dtype", dtype), tool="peer_selftest")
+    assert out.count("bit-identical") == 2, out[-2000:]
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_fp8_shards_across_processes_on_one_device(world):
     """attn_dtype = fp8 under frame sharding between real processes (one device): the QUANTISED shards travel through the copy-engine

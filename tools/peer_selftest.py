@@ -31,6 +31,8 @@ def main():
                     "anything else, so that the ranks' identical allocation sequences do NOT end up at identical virtual addresses")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the engines exchange QUANTISED shards (half the bytes) and "
                     "run the fp8 two-pass attention; asserted through am_attention_counters")
+    ap.add_argument("--loop", default="c", choices=["c", "python", "both"], help="who drives the per-layer phases: the C entry point "
+                    "am_forward_sharded_peer (product), sharding.sharded_forward's Python loop, or both alternately with the outputs compared bit for bit")
     ap.add_argument("--defer", type=int, default=8, help="attention kernel form: 8 lazy (product), 28 exact, 0 exact / immediate re-base")
     a = ap.parse_args()
     from actionmesh_amd import ClassifierFreeGuidance
@@ -133,9 +135,16 @@ def main():
             v_local, tr = traced_forward()
             traces.append(tr)
         else:
+            mode = a.loop if a.loop != "both" else ("python" if len(outs) % 2 == 0 else "c")
+            os.environ["ACTIONMESH_AMD_PHASE_LOOP"] = "python" if (a.serial or mode == "python") else "c"
             v_local = sharded_forward(eng, plan, dist.group.WORLD, plan.slice_frames(x_in.to(dev)), t_local, exchange=eng.exchange)
         torch.cuda.synchronize(dev)
         outs.append(v_local.float().cpu())
+    if a.loop == "both" and not (a.trace or a.ktrace or a.serial):
+        same = all(torch.equal(o, outs[0]) for o in outs[1:])
+        print(f"[peer_selftest] rank {rank}: C phase loop vs Python phase loop, {len(outs)} alternating forwards: "
+              f"{'bit-identical' if same else 'DIFFER'}", flush=True)
+        assert same and len(outs) >= 2
     if a.trace:
         for k in range(1, len(traces)):
             first = next((e for e, e0 in zip(traces[k], traces[0]) if e != e0), None)

@@ -170,3 +170,32 @@ def test_folded_projection_with_fused_head_split():
     lin = ops.gemm(x, wf, bias=d, ln=(st, colsum))
     q0, k0, vt0 = ops.head_post(lin, heads, (0, 1, 2), T * L, L, w_q=wq, w_k=wk)
     assert torch.equal(q, q0) and torch.equal(k, k0) and torch.equal(vt, vt0)
+
+
+def test_canonical_row_statistics_against_the_numpy_restatement():
+    """oracle/row_stats_oracle.py restates the canonical definition (groups of 8, balanced tree of equal-count merges, slices left to
+    right) in numpy binary32.  Every producer must give ITS bits: the per-slice (mean, M2) a GEMM's store loop writes and the ones the
+    read-back pass writes, exactly; the merged mean exactly; rstd to 2 ulp (the device's rsqrt is not the correctly rounded
+    1 / sqrt)."""
+    import numpy as np
+    from oracle import row_stats_oracle as RO
+    M, N, K = 2048 + 32, 1024, 256                      # 2048 rows through the store loop, 32 through the read-back pass
+    a = rnd(M, K, seed=21, scale=1.3)
+    w = rnd(N, K, seed=22, scale=K ** -0.5)
+    r = rnd(M, N, seed=23, scale=2.0, shift=1.5)
+    part = torch.empty((M, N // 256, 2), dtype=torch.float32, device=DEV)
+    out = ops.gemm(a, w, residual=r, force_big=True, ln_part=part)
+    mean, rstd, parts = RO.row_stats(out.float().cpu().numpy())
+    got = part.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), parts.view(np.uint32)), int((got.view(np.uint32) != parts.view(np.uint32)).sum())
+    for st in (ops.row_stats_finalize(part, N), ops.row_stats(out)):
+        st = st.cpu().numpy()
+        assert np.array_equal(st[:, 0].view(np.uint32), mean.view(np.uint32))
+        ulp = np.abs(st[:, 1].view(np.int32).astype(np.int64) - rstd.view(np.int32).astype(np.int64))
+        assert int(ulp.max()) <= 2, int(ulp.max())
+    gamma = torch.rand(N, device=DEV) + 0.5
+    beta = torch.randn(N, device=DEV) * 0.3
+    st = torch.empty((M, 2), dtype=torch.float32, device=DEV)
+    y = ops.layernorm(out, gamma, beta, stats_out=st)
+    m2, _, _ = RO.row_stats(y.float().cpu().numpy())
+    assert np.array_equal(st[:, 0].cpu().numpy().view(np.uint32), m2.view(np.uint32))

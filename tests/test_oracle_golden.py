@@ -129,3 +129,20 @@ def test_step_flops_match_survey():
     head = O.OracleConfig(width=1024, num_attention_heads=8)
     assert O.step_flops(2, 16, 4096, head, 257) == pytest.approx(8.2922e14, rel=2e-4)
     assert O.step_flops(2, 64, 8192, head, 257) == pytest.approx(4.8016e16, rel=2e-4)
+
+
+def test_row_stats_oracle_against_float64():
+    """oracle/row_stats_oracle.py (the canonical LayerNorm row statistics of the folded LayerNorms, restated in numpy binary32) agrees
+    with float64 statistics to binary32 accuracy, rows far from zero included; the GPU test holds the kernels to ITS bits."""
+    import numpy as np
+    from oracle import row_stats_oracle as RO
+    rng = np.random.default_rng(0)
+    for C, shift in ((256, 0.0), (1024, 5.0), (2048, -40.0)):
+        x = (rng.standard_normal((33, C)) * 3 + shift).astype(np.float32)
+        mean, rstd, parts = RO.row_stats(x)
+        x64 = x.astype(np.float64)
+        assert np.allclose(mean, x64.mean(1), rtol=0, atol=2e-6 * max(1.0, abs(shift)))
+        assert np.allclose(rstd, 1.0 / np.sqrt(x64.var(1) + 1e-5), rtol=3e-6)
+        assert parts.shape == (33, C // 256, 2)
+        sl = x64[:, :256]
+        assert np.allclose(parts[:, 0, 1], ((sl - sl.mean(1, keepdims=True)) ** 2).sum(1), rtol=3e-6)

@@ -396,8 +396,6 @@ def gather_latent_frames(latents: torch.Tensor, plan: FrameShardPlan, group: Opt
         return latents
     assert latents.is_contiguous() and latents.shape[0] == plan.n_frames
     view = latents.view((plan.frame_world, plan.frames_local) + tuple(latents.shape[1:]))
-    if latents.is_cuda and dist.get_backend(group) == "gloo":
-        _all_gather_flat(view, view[plan.frame_rank].clone(), group)
-    else:
-        dist.all_gather_into_tensor(view.view(-1), view[plan.frame_rank].reshape(-1), group=group)
+    # once per sampling run: a private copy of the local frames as the send buffer (no reliance on in-place all-gather semantics)
+    _all_gather_flat(view, view[plan.frame_rank].clone(), group)
     return latents

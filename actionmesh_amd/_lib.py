@@ -190,6 +190,25 @@ def kind_of(dtype) -> str:
     raise ValueError(f"actionmesh_amd: the 16-bit type must be bfloat16 or float16, got {dtype!r}")
 
 
+def autocast_kind(pinned: Optional[str] = None) -> str:
+    """'bf16' or 'f16' for a module called like the reference's: the pinned kind if there is one, else the dtype of the caller's
+    torch.autocast("cuda", dtype) region - the reference pipeline runs Stage I and Stage II inside one (pipeline.py:671, 679) with the
+    CLI's --dtype {bfloat16, float16} - and bfloat16 outside any region.  float16 is chosen only when the caller asked for it."""
+    if pinned is not None:
+        return pinned
+    import torch
+    if hasattr(torch, "get_autocast_dtype"):
+        enabled, dt = torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda")
+    else:                                    # older torch: the per-device getters (ADVICE r04: no silent bf16 under autocast(float16))
+        enabled, dt = torch.is_autocast_enabled(), torch.get_autocast_gpu_dtype()
+    return "f16" if (enabled and dt == torch.float16) else "bf16"
+
+
+def torch_dtype(kind: str):
+    import torch
+    return torch.float16 if kind == "f16" else torch.bfloat16
+
+
 def check(status: int, what: str = "", l: Optional[C.CDLL] = None) -> None:
     if status != 0:
         msg = (l if l is not None else lib()).am_last_error().decode(errors="replace")

@@ -401,14 +401,7 @@ class HipDenoiser(nn.Module):
 
     def compute_kind(self) -> str:
         """'bf16' or 'f16': the pinned dtype, else the autocast dtype of the calling region (float16 only when the caller asked for it)."""
-        if self.dtype_pinned is not None:
-            return self.dtype_pinned
-        try:
-            if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
-                return "f16"
-        except Exception:
-            pass
-        return "bf16"
+        return L.autocast_kind(self.dtype_pinned)
 
     def _ensure_engine(self, B: int, T_local: int, N: int, S: int, plan: FrameShardPlan) -> HipEngine:
         if self._host_sd is None:

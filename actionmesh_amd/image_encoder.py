@@ -28,6 +28,7 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
+from . import _lib as L
 from . import ops
 from ._lib import lib
 
@@ -103,8 +104,16 @@ def position_rows(pos: torch.Tensor, cls: torch.Tensor, trained_side: int, n_h: 
 
 class HipImageEncoder:
     def __init__(self, pretrained_dino_feature_extractor: Optional[str] = None, pretrained_dino_model: Optional[str] = None,
-                 config: Optional[Dict] = None, state_dict: Optional[Dict[str, torch.Tensor]] = None, **_ignored):
+                 config: Optional[Dict] = None, state_dict: Optional[Dict[str, torch.Tensor]] = None, dtype=None, **_ignored):
         lib()      # fail loudly here if libactionmesh_amd.so is missing
+        # 16-bit storage type.  The reference encodes OUTSIDE its autocast region, in fp32 (pipeline.py:665-667): there is no caller dtype
+        # to follow, so the default is bfloat16 (fp32's exponent range: safe for DINOv2's outlier tokens whatever the checkpoint) and
+        # dtype="float16" selects the float16 build - 8x finer rounding, measured closer to the fp32 reference on the ViT-L/14 fixture
+        # (tests/test_image_encoder.py::test_hip_encoder_vitl_against_transformers); anything else is refused (there is no fp32 library).
+        self.kind = "bf16" if dtype is None else L.kind_of(dtype)
+        if self.kind == "f16":
+            lib("f16")
+        self.dt16 = L.torch_dtype(self.kind)
         self.pretrained_dino_feature_extractor = pretrained_dino_feature_extractor
         self.pretrained_dino_model = pretrained_dino_model
         self._device = torch.device("cpu")
@@ -171,7 +180,7 @@ class HipImageEncoder:
 
     def _upload(self) -> None:
         dev = self._device
-        self._w = {k: v.to(dev, torch.float32 if (k.endswith(".b") or k.startswith("norm") or ".norm" in k) else torch.bfloat16).contiguous()
+        self._w = {k: v.to(dev, torch.float32 if (k.endswith(".b") or k.startswith("norm") or ".norm" in k) else self.dt16).contiguous()
                    for k, v in self._packed.items() if k not in ("pos", "cls")}
         self._pos_cache.clear()
 
@@ -180,14 +189,14 @@ class HipImageEncoder:
         if key not in self._pos_cache:
             side = self.cfg["image_size"] // self.cfg["patch_size"]
             rows = position_rows(self._packed["pos"], self._packed["cls"], side, n_h, n_w)
-            self._pos_cache = {key: rows.to(self._device, torch.bfloat16)[None].expand(T, -1, -1).reshape(T * rows.shape[0], -1).contiguous()}
+            self._pos_cache = {key: rows.to(self._device, self.dt16)[None].expand(T, -1, -1).reshape(T * rows.shape[0], -1).contiguous()}
         return self._pos_cache[key]
 
     # ---- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_pixels(self, pixel_values: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """Dinov2Model(pixel_values).last_hidden_state: (T, 3, H, W) -> (T, 1 + (H/p)(W/p), C).
-        `out_dtype=torch.bfloat16` hands the context over in the dtype `am_set_context` stores it in."""
+        `out_dtype=torch.bfloat16` (the encoder's own 16-bit type) hands the context over in the dtype `am_set_context` stores it in."""
         if self._device.type != "cuda" or not self._w:
             raise RuntimeError("HipImageEncoder: load_state_dict(...) and .to('cuda:N') first (there is no CPU path)")
         cfg, w, dev = self.cfg, self._w, self._device
@@ -200,14 +209,15 @@ class HipImageEncoder:
         with torch.cuda.device(dev):
             pix = pixel_values.to(dev, torch.float32).contiguous()
             pos = self._pos_rows(T, n_h, n_w)
-            h = torch.empty((T * S, C), dtype=torch.bfloat16, device=dev)
-            ops.gemm(ops.patchify(pix, p, w["patch.w"].shape[1]), w["patch.w"], bias=w["patch.b"], residual=pos, out=h,
+            dt16 = self.dt16
+            h = torch.empty((T * S, C), dtype=dt16, device=dev)
+            ops.gemm(ops.patchify(pix, p, w["patch.w"].shape[1], dtype=dt16), w["patch.w"], bias=w["patch.b"], residual=pos, out=h,
                      c_map=(npatch, S, 1), M=T * npatch)
             h.view(T, S, C)[:, 0] = pos[0]                                        # class token + its position
             HP = ops.HEAD_DIM
-            Q = torch.zeros((T, H, ops.round_up(S, 256), HP), dtype=torch.bfloat16, device=dev)
-            K = torch.zeros((T, H, ops.round_up(S, 64), HP), dtype=torch.bfloat16, device=dev)
-            Vt = torch.zeros((T, H, HP, ops.round_up(S, 64)), dtype=torch.bfloat16, device=dev)
+            Q = torch.zeros((T, H, ops.round_up(S, 256), HP), dtype=dt16, device=dev)
+            K = torch.zeros((T, H, ops.round_up(S, 64), HP), dtype=dt16, device=dev)
+            Vt = torch.zeros((T, H, HP, ops.round_up(S, 64)), dtype=dt16, device=dev)
             scale = float(C // H) ** -0.5
             for i in range(cfg["num_hidden_layers"]):
                 q = f"l{i}."
@@ -220,7 +230,7 @@ class HipImageEncoder:
                 f = ops.gemm(z, w[q + "fc1.w"], bias=w[q + "fc1.b"], gelu=True)
                 h = ops.gemm(f, w[q + "fc2.w"], bias=w[q + "fc2.b"], residual=h)
             y = ops.layernorm(h, w["norm.w"], w["norm.b"], eps=eps).view(T, S, C)
-            return y if out_dtype == torch.bfloat16 else y.to(out_dtype)
+            return y if out_dtype == y.dtype else y.to(out_dtype)
 
     def encode_images(self, images: List) -> torch.Tensor:
         """image_encoder.py:38-55: T PIL images -> context (T, S, Dc)."""

@@ -353,30 +353,30 @@ def timestep_sinusoid(t: torch.Tensor, width: int) -> torch.Tensor:
 
 
 def point_embed(query: torch.Tensor, in_channels: int, extra_channels: int, num_freqs: int, include_pi: bool,
-                ld_out: int = 64) -> torch.Tensor:
-    """query (rows, >= in+extra) fp32 -> bf16 (rows, ld_out): FrequencyPositionalEmbedding + extras, zero padded."""
+                ld_out: int = 64, dtype=torch.bfloat16) -> torch.Tensor:
+    """query (rows, >= in+extra) fp32 -> 16-bit (rows, ld_out): FrequencyPositionalEmbedding + extras, zero padded."""
     _need(query, torch.float32, "query")
     rows = query.shape[0]
-    out = torch.empty((rows, ld_out), dtype=torch.bfloat16, device=query.device)
-    _launch(query, L.lib().am_point_embed, "am_point_embed", query.data_ptr(), query.stride(0), rows, in_channels, extra_channels, num_freqs,
+    out = torch.empty((rows, ld_out), dtype=dtype, device=query.device)
+    _launch(query, _fn(dtype, "am_point_embed"), "am_point_embed", query.data_ptr(), query.stride(0), rows, in_channels, extra_channels, num_freqs,
                                    int(include_pi), out.data_ptr(), ld_out)
     return out
 
 
-def patchify(pixels: torch.Tensor, patch: int, ld_out: int) -> torch.Tensor:
-    """pixels (T, C, H, W) fp32 -> bf16 (T * (H // patch) * (W // patch), ld_out): rows of the kernel = stride patch
+def patchify(pixels: torch.Tensor, patch: int, ld_out: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """pixels (T, C, H, W) fp32 -> 16-bit (T * (H // patch) * (W // patch), ld_out): rows of the kernel = stride patch
     convolution in flattened-Conv2d-weight column order, zero padded."""
     _need(pixels, torch.float32, "pixels")
     T, Cin, H, W = pixels.shape
-    out = torch.empty((T * (H // patch) * (W // patch), ld_out), dtype=torch.bfloat16, device=pixels.device)
-    _launch(pixels, L.lib().am_patchify, "am_patchify", pixels.data_ptr(), T, Cin, H, W, patch, out.data_ptr(), ld_out)
+    out = torch.empty((T * (H // patch) * (W // patch), ld_out), dtype=dtype, device=pixels.device)
+    _launch(pixels, _fn(dtype, "am_patchify"), "am_patchify", pixels.data_ptr(), T, Cin, H, W, patch, out.data_ptr(), ld_out)
     return out
 
 
 def displacement(logits: torch.Tensor, out_dim: int, out: torch.Tensor) -> torch.Tensor:
     """out (rows, out_dim) fp32 = 2 sigmoid(-logits[:, :out_dim]) - 1."""
-    _need(logits, torch.bfloat16, "logits"); _need(out, torch.float32, "out")
-    _launch(logits, L.lib().am_displacement, "am_displacement", logits.data_ptr(), logits.stride(0), logits.shape[0], out_dim, out.data_ptr())
+    _need(logits, H16, "logits"); _need(out, torch.float32, "out")
+    _launch(logits, _fn(logits, "am_displacement"), "am_displacement", logits.data_ptr(), logits.stride(0), logits.shape[0], out_dim, out.data_ptr())
     return out
 
 

@@ -337,6 +337,90 @@ def denoiser_forward(sd: Dict[str, Tensor], cfg: OracleConfig, hidden_states: Te
     return (v, inter) if return_intermediates else v
 
 
+def denoiser_forward_rows(sd: Dict[str, Tensor], cfg: OracleConfig, hidden_states: Tensor, context: Tensor,
+                          framestep: Tensor, diffusion_time: Tensor, mask: Optional[Tensor], rows: Tensor,
+                          frame_chunk: int = 4) -> Tensor:
+    """denoiser_forward (fp32) restricted to SELECTED latent tokens of a ONE-layer model - the same statements in the same order,
+    evaluated only where the selected rows need them, so that a sequence of 524 352 tokens (BASELINE configs[4]: 64 frames x 8192
+    tokens) is checkable on host cores in seconds instead of hours: in a one-layer model everything except the inflated
+    self-attention is per token (temporal_denoiser.py:205-217, block.py:137-152, temporal_denoiser.py:239-247), and the
+    self-attention of a row needs the K / V of every token of its sample (attention_processor.py:92-139) but the Q of that row only.
+    rows: int64 (R, 3) of (b, t, n), n indexing the N latent tokens of frame t.  Returns the velocity (R, Din).
+    Checked against denoiser_forward itself in tests/test_oracle_golden.py::test_forward_rows_is_the_full_forward_on_those_rows."""
+    assert cfg.num_layers == 1 and not cfg.has_skip(0), "one layer, no skip: the only block whose inputs are per-token"
+    P = Precision("fp32")
+    B, T, N, Din = hidden_states.shape
+    C, H, hd, L = cfg.width, cfg.num_attention_heads, cfg.head_dim, N + 1
+    p = "blocks.0."
+    inflate = 0 in cfg.inflated_layers
+    cos, sin = rope_tables(framestep, hd)                                   # (B*T, hd)  temporal_denoiser.py:196-202
+    t_bt = diffusion_time.repeat(T)                                         # :209-212
+    if mask is not None:
+        t_bt = t_bt * (1 - mask.reshape(B * T))
+    e = timestep_sinusoid(t_bt, C)                                          # :213
+    e = P.linear(e, sd["time_proj.linear_1.weight"], sd["time_proj.linear_1.bias"])
+    e = F.gelu(e, approximate="none")
+    e = P.linear(e, sd["time_proj.linear_2.weight"], sd["time_proj.linear_2.bias"])   # :214  (B*T, C)
+
+    def frames_h0(b: int, t0: int, t1: int) -> Tensor:
+        """rows of `h` (:217) for frames [t0, t1) of sample b: (t1 - t0, L, C)."""
+        hh = P.linear(hidden_states[b, t0:t1], sd["proj_in.weight"], sd["proj_in.bias"])   # :205-206
+        return torch.cat([e[b * T + t0:b * T + t1, None, :], hh], dim=1)
+
+    def heads_of(z: Tensor, cs: Tensor, sn: Tensor):
+        """q, k, v (rows, H, hd) of normalised tokens z (rows, C) with their frames' RoPE rows cs / sn (rows, hd):
+        attention_processor.py:92-130 - the per-head split of the CONCATENATED projection, qk RMSNorm, RoPE."""
+        q = P.linear(z, sd[p + "s_attn.to_q.weight"], None)
+        k = P.linear(z, sd[p + "s_attn.to_k.weight"], None)
+        v = P.linear(z, sd[p + "s_attn.to_v.weight"], None)
+        q, k, v = torch.split(torch.cat((q, k, v), dim=-1).view(-1, H, 3 * hd), hd, dim=-1)
+        q = rms_norm(q, sd[p + "s_attn.norm_q.weight"])
+        k = rms_norm(k, sd[p + "s_attn.norm_k.weight"])
+        # apply_rope takes (B, H, S, D) with cos / sin (B, S, D): one "batch", S = rows
+        q = apply_rope(q.transpose(0, 1)[None], cs[None], sn[None])[0].transpose(0, 1)
+        k = apply_rope(k.transpose(0, 1)[None], cs[None], sn[None])[0].transpose(0, 1)
+        return q, k, v
+
+    out = torch.empty((rows.shape[0], Din), dtype=torch.float32)
+    for b in sorted(set(int(x) for x in rows[:, 0])):
+        sel = (rows[:, 0] == b).nonzero()[:, 0]
+        rt, rn = rows[sel, 1], rows[sel, 2]
+        R = sel.numel()
+        # ---- the selected rows' own hidden state (token index 1 + n of frame t) -------------------------------------------
+        h = torch.stack([frames_h0(b, int(t), int(t) + 1)[0, 1 + int(n)] for t, n in zip(rt, rn)])           # (R, C)
+        z = fp32_layer_norm(h, sd[p + "norm_s_attn.weight"], sd[p + "norm_s_attn.bias"])                      # block.py:138
+        q, _, _ = heads_of(z, cos[b * T + rt], sin[b * T + rt])                                             # (R, H, hd)
+        # ---- K / V of every token this row attends to: the whole sample when inflated, else its own frame ----------------
+        o = torch.zeros((R, H, hd))
+        if inflate:
+            K = torch.empty((H, T * L, hd)); V = torch.empty((H, T * L, hd))
+            for t0 in range(0, T, frame_chunk):
+                t1 = min(T, t0 + frame_chunk)
+                zz = fp32_layer_norm(frames_h0(b, t0, t1), sd[p + "norm_s_attn.weight"], sd[p + "norm_s_attn.bias"]).reshape(-1, C)
+                cs = cos[b * T + t0:b * T + t1].repeat_interleave(L, dim=0)
+                sn = sin[b * T + t0:b * T + t1].repeat_interleave(L, dim=0)
+                _, k, v = heads_of(zz, cs, sn)
+                K[:, t0 * L:t1 * L] = k.transpose(0, 1); V[:, t0 * L:t1 * L] = v.transpose(0, 1)
+            s = torch.einsum("rhd,hkd->hrk", q, K) * hd ** -0.5                                               # :133-139
+            o = torch.einsum("hrk,hkd->rhd", torch.softmax(s, dim=-1), V)
+        else:
+            for j in range(R):
+                t = int(rt[j])
+                zz = fp32_layer_norm(frames_h0(b, t, t + 1), sd[p + "norm_s_attn.weight"], sd[p + "norm_s_attn.bias"]).reshape(-1, C)
+                _, k, v = heads_of(zz, cos[b * T + t].expand(L, hd), sin[b * T + t].expand(L, hd))
+                s = torch.einsum("hd,khd->hk", q[j], k) * hd ** -0.5
+                o[j] = torch.einsum("hk,khd->hd", torch.softmax(s, dim=-1), v)
+        h = h + P.linear(o.reshape(R, C), sd[p + "s_attn.to_out.0.weight"], sd[p + "s_attn.to_out.0.bias"])   # :147, block.py:137
+        z = fp32_layer_norm(h, sd[p + "norm_x_attn.weight"], sd[p + "norm_x_attn.bias"])
+        h = h + cross_attention(z[:, None], context[b, rt], sd, p + "x_attn.", H, P)[:, 0]                    # block.py:146-149
+        z = fp32_layer_norm(h, sd[p + "norm_ff.weight"], sd[p + "norm_ff.bias"])
+        u = F.gelu(P.linear(z, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"]), approximate="none")
+        h = h + P.linear(u, sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"])                               # block.py:152
+        h = fp32_layer_norm(h, sd["norm_out.weight"], sd["norm_out.bias"])                                    # :239-242
+        out[sel] = P.linear(h, sd["proj_out.weight"], sd["proj_out.bias"])
+    return out
+
+
 # ----------------------------------------------------------------------------
 # L3: sampler (scheduler.py, guidance.py)
 # ----------------------------------------------------------------------------

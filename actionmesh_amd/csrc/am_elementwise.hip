@@ -14,7 +14,7 @@ void am_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* am_last_error(void) { return g_err; }
-extern "C" int am_abi_version(void) { return 1; }
+extern "C" int am_abi_version(void) { return 2; }
 
 namespace {
 

@@ -236,10 +236,18 @@ class HipEngine:
         v = torch.empty((B, T, N, D), dtype=self.h16, device=self.device)
         infl = (C.c_uint8 * self.num_layers)(*[1 if self.is_inflated(i) else 0 for i in range(self.num_layers)])
         ring = ex.ring()
-        with torch.cuda.device(self.device):
-            self._check(self.lib.am_forward_sharded_peer(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(), C.byref(ring), infl,
-                                                         self.num_layers, self._stream()), "am_forward_sharded_peer")
-        ex.sync_seq()
+        ok = False
+        try:
+            with torch.cuda.device(self.device):
+                self._check(self.lib.am_forward_sharded_peer(self.handle, x_local.data_ptr(), t, B, T, N, v.data_ptr(), C.byref(ring), infl,
+                                                             self.num_layers, self._stream()), "am_forward_sharded_peer")
+            ok = True
+        finally:
+            # ring->seq has advanced by every exchange the call got through, whether it returned an error or not: the Python counter
+            # follows it in every case; after an error the flag state of the peers is unknown, so the exchange is poisoned
+            ex.sync_seq()
+            if not ok:
+                ex.poisoned = True
         self._x_keepalive = x_local
         return v
 
@@ -386,8 +394,9 @@ class HipDenoiser(nn.Module):
             return self.process_group
         if plan.cfg_groups not in self._frame_groups:
             base = dist.get_process_group_ranks(self.process_group)
+            be = dist.get_backend(self.process_group)      # sub-groups on the SAME backend as the group handed in, not the default group's
             self._frame_groups[plan.cfg_groups] = [
-                dist.new_group([base[r] for r in plan.frame_group_ranks(g)]) for g in range(plan.cfg_groups)]
+                dist.new_group([base[r] for r in plan.frame_group_ranks(g)], backend=be) for g in range(plan.cfg_groups)]
         return self._frame_groups[plan.cfg_groups][plan.cfg_rank]
 
     def _cfg_peer_group(self, plan: FrameShardPlan):
@@ -395,8 +404,9 @@ class HipDenoiser(nn.Module):
         only ranks a sampler that keeps its latents sharded has to hear from in a step (forward_host_time(gather=False))."""
         if plan.cfg_groups not in self._cfg_peer_groups:
             base = dist.get_process_group_ranks(self.process_group)
+            be = dist.get_backend(self.process_group)
             self._cfg_peer_groups[plan.cfg_groups] = [
-                dist.new_group([base[r] for r in plan.cfg_peer_ranks(i)]) for i in range(plan.group_size)]
+                dist.new_group([base[r] for r in plan.cfg_peer_ranks(i)], backend=be) for i in range(plan.group_size)]
         return self._cfg_peer_groups[plan.cfg_groups][plan.rank % plan.group_size]
 
     def compute_kind(self) -> str:

@@ -194,7 +194,10 @@ class HipSchedulerFlow:
                 ops.flow_step(v, latents[0][fsl], scales, dt, self.is_additive, unobs_step)
                 if local_latents and i == self.num_inference_steps - 1:
                     diffusion_model.gather_latent_frames(latents[0], 1 if split else nb)
-            diffusion_model.check_exchange(block=False)      # copy-engine exchange: last step's fault word, no device sync
+            # copy-engine exchange: the previous step's fault word without a device sync - except BEHIND THE LAST STEP, where the verdict
+            # is taken blocking before the final latents are handed out (a caller that drives this generator directly gets it too;
+            # the deferred word used to leave the last step of such a caller unchecked)
+            diffusion_model.check_exchange(block=(i == self.num_inference_steps - 1))
             yield latents, timesteps[i]
 
     @torch.no_grad()

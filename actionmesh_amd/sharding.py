@@ -167,7 +167,11 @@ class PeerExchange:
             self.kv = C.c_void_p()
             L.check(self.lib.am_peer_alloc(self.P * self.chunk_bytes, C.byref(self.kv)), "am_peer_alloc")
             self.flags = C.c_void_p()                       # uint32: arrived[P] | consumed[P] | fault
-            L.check(self.lib.am_peer_alloc(4 * (2 * self.P + 1), C.byref(self.flags)), "am_peer_alloc")
+            # FINE-GRAINED device memory: the block is polled by this device's kernels while a peer DEVICE writes it (am_peer.hip)
+            fine = C.c_int(0)
+            L.check(self.lib.am_peer_alloc_flags(4 * (2 * self.P + 1), C.byref(self.flags), C.byref(fine)), "am_peer_alloc_flags")
+            self.flags_fine_grained = bool(fine.value)
+            self.poisoned = False                           # set when a C-driven forward failed mid-loop: the flag state is unknown
             hk, hf = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
             L.check(self.lib.am_peer_export(self.kv, hk), "am_peer_export")
             L.check(self.lib.am_peer_export(self.flags, hf), "am_peer_export")
@@ -193,6 +197,9 @@ class PeerExchange:
     def ring(self):
         """This rank's view of the exchange as the C struct of include/actionmesh_amd_sharded.h (am_forward_sharded_peer: the phase loop
         in C).  The struct shares the sequence counter with this object: `sync_seq()` after a C-driven forward."""
+        if self.poisoned:
+            raise RuntimeError("PeerExchange: an earlier forward failed inside the phase loop; the sequence flags of the ring are in an "
+                               "unknown state - rebuild the engine (HipDenoiser does on the next forward after close())")
         if getattr(self, "_ring", None) is None:
             r = self.L.AmPeerRing()
             r.world, r.rank, r.chunk_bytes = self.P, self.me, self.chunk_bytes
@@ -215,6 +222,8 @@ class PeerExchange:
         return base + 4 * (self.P + reader)
 
     def start(self) -> None:
+        if self.poisoned:
+            raise RuntimeError("PeerExchange: poisoned by an earlier failed forward; rebuild the engine")
         self.seq += 1
         comp = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
@@ -281,6 +290,9 @@ class PeerExchange:
         torch.cuda.synchronize(self.device)
         if collective and self._group is not None:
             dist.barrier(group=self._group)
+        if getattr(self, "_ring", None) is not None:
+            self.lib.am_peer_ring_destroy(self.C.byref(self._ring))     # the two events the ring owns
+            self._ring = None
         for ptr in list(self.peer_kv.values()) + list(self.peer_flags.values()):
             self.lib.am_peer_close(ptr)
         self.lib.am_peer_free(self.kv)
@@ -399,3 +411,40 @@ def gather_latent_frames(latents: torch.Tensor, plan: FrameShardPlan, group: Opt
     # once per sampling run: a private copy of the local frames as the send buffer (no reliance on in-place all-gather semantics)
     _all_gather_flat(view, view[plan.frame_rank].clone(), group)
     return latents
+
+
+def run_exchange_legs(order, run_leg, ctl_group, rank: int, leg_timeout: float, on_watchdog, describe=None):
+    """Run the exchange back-ends named in `order` one after the other on every rank and agree on which of them completed.
+
+    `run_leg(name)` does one leg on this rank and returns its result (any object) or raises.  After every leg the ranks take the MIN
+    of their success flags over `ctl_group` (a gloo group: the control plane must not depend on the back-end under test), so a leg
+    counts only if EVERY rank completed it; a leg that failed anywhere is reported with its error text and the next one runs.
+    From the second leg on - i.e. once there is something to report - a watchdog thread calls `on_watchdog(name, legs, report)`
+    when a leg has produced no verdict after `leg_timeout` seconds (a collective that never returns cannot be caught): the caller
+    prints what it has and leaves the process.  Rank 0's watchdog fires first, the other ranks' 10 s later.
+    Returns (legs: name -> result of the legs that completed everywhere, report: name -> {"ok": bool, ...}).
+    `describe(result)` -> dict of extra fields for the report of a completed leg.  Used by bench.py --gpus N;
+    tests/test_sharding_gloo.py drives it with stand-in legs between two gloo processes."""
+    import threading
+    legs, report = {}, {}
+    for i, name in enumerate(order):
+        timer = None
+        if i > 0 and legs:
+            timer = threading.Timer(leg_timeout + (0.0 if rank == 0 else 10.0), on_watchdog, args=(name, legs, report))
+            timer.daemon = True
+            timer.start()
+        result, err = None, None
+        try:
+            result = run_leg(name)
+        except Exception as e:                       # noqa: BLE001 - the verdict of a leg, reported instead of raised
+            err = f"{type(e).__name__}: {str(e)[:300]}"
+        flag = torch.tensor([1 if err is None else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl_group)
+        if timer is not None:
+            timer.cancel()
+        if bool(flag.item()):
+            legs[name] = result
+            report[name] = {"ok": True, **(describe(result) if describe is not None else {})}
+        else:
+            report[name] = {"ok": False, "error": err or "failed on another rank"}
+    return legs, report

@@ -92,7 +92,7 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
+def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16", groups=None):
     """Time the dominant kernel (inflated self-attention, both CFG samples) with HIP events on the
     launch stream.  One launch = one layer on one rank: this rank's T/world frames of queries
     against all T frames of keys; algorithmic flops per launch = 4 * (T*L/world) * (T*L) * (H*128) * B
@@ -102,7 +102,8 @@ def attention_roofline(T, N, H, dev, world=1, reps=3, dtype="bf16"):
     trained qk-norm gains look like): the lazy re-base branch of the kernel then fires on most rows and a few workgroups
     go through the exact fallback, so the pair brackets the data-dependent cost of the product kernel."""
     from actionmesh_amd import ops
-    groups = 2 if world % 2 == 0 else 1          # CFG branches split first (sharding.FrameShardPlan)
+    if groups is None:
+        groups = 2 if world % 2 == 0 else 1      # CFG branches split first (sharding.FrameShardPlan)
     fw = world // groups                         # frame shards per branch = key chunks
     B, L = 2 // groups, N + 1
     Sq = (T // fw) * L               # local query rows == keys per chunk
@@ -463,11 +464,23 @@ def main():
     ap.add_argument("--cpu-baseline-deep", action="store_true",
                     help="cpu_baseline: add the N = 2048 sample (TL = 32 784; minutes of host time) so the fit is evaluated x2 instead of "
                          "x4 beyond its largest sample.  Off by default: the default run has to finish within a few minutes")
+    ap.add_argument("--exchange", default=None, choices=["ab", "rccl", "peer"],
+                    help="N > 1: the per-layer [K | V^T] exchange back-end.  Default `ab`: BOTH back-ends inside this one invocation - first the "
+                         "RCCL (`rccl`: all_gather_into_tensor on the nccl backend), then the copy-engine one (`peer`: SDMA pushes between IPC-mapped "
+                         "buffers, gloo control plane: no RCCL call at all) - `value` is the faster leg that completed, both timings are in "
+                         "`exchange_ab`, and a leg that raises or outlives --leg-timeout is reported there instead of killing the run "
+                         "(VERDICT r04 next #2).  The ACTIONMESH_AMD_EXCHANGE environment variable, when set, selects one leg.")
+    ap.add_argument("--cfg-parallel", type=int, default=1, choices=[0, 1],
+                    help="N > 1: 1 (default) = the two guidance branches go to the two halves of the ranks, frames are sharded inside a half; "
+                         "0 = north_star's pure frame sharding (every rank computes both branches of T / N frames)")
+    ap.add_argument("--leg-timeout", type=float, default=420.0,
+                    help="N > 1, second leg of --exchange ab: seconds before a watchdog prints the line with the completed leg and exits")
+    ap.add_argument("--no-fingerprint-check", action="store_true",
+                    help="N > 1: skip the single-rank re-run of the same steps on rank 0 that the sharded latents are compared with")
     args = ap.parse_args()
     if args.graph:
         os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
     if args.same_device:
-        os.environ["ACTIONMESH_AMD_EXCHANGE"] = "peer"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch.distributed as dist
@@ -482,24 +495,21 @@ def main():
         local_rank = 0
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    group = None
-    backend = "gloo" if args.same_device else "nccl"
+    # ---- process groups.  WORLD: nccl (= RCCL; lazy communicator creation on the current device - no device_id: eager init would create
+    # the CFG-branch sub-groups by communicator split, which not every RCCL build supports), gloo for --same-device (RCCL refuses two
+    # ranks on one device).  `ctl`: a gloo group of all ranks for everything that is not the data path - barriers, the MAX of the
+    # timings, the per-leg verdicts - so that a broken RCCL cannot take the control plane with it.
+    ctl = None
     if world > 1:
-        # lazy communicator creation on the current device (no device_id: eager init would create the CFG-branch
-        # sub-groups by communicator split, which not every RCCL build supports)
-        dist.init_process_group(backend)
-        group = dist.group.WORLD
-    ctl_dev = torch.device("cpu") if backend == "gloo" else dev      # where the control-plane tensors (timing all-reduce) live
+        dist.init_process_group("gloo" if args.same_device else "nccl")
+        ctl = dist.group.WORLD if args.same_device else dist.new_group(backend="gloo")
 
     def barrier():
-        if backend == "nccl":
-            dist.barrier(device_ids=[local_rank])
-        else:
-            dist.barrier()
+        dist.barrier(group=ctl)
 
     def max_over_ranks(seconds):
-        tmax = torch.tensor([seconds], device=ctl_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([seconds], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
         return float(tmax.item())
 
     T, N, C, H, NL, S, Dc, Din = SHAPES[args.shape]
@@ -511,124 +521,214 @@ def main():
     hp = dict(in_channels=Din, num_layers=NL, num_attention_heads=H, width=C, mlp_ratio=4.0,
               cross_attention_dim=Dc, inflated_layers=list(range(NL)))
     sd = random_state_dict(hp, seed=0)
-    model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, attn_dtype=args.dtype, **hp)
-    model.load_state_dict(sd)
-    model.to(dev).eval()
-
     g = torch.Generator().manual_seed(0)
-    init_latent = torch.randn(1, T, N, Din, generator=g).to(dev)
+    init_latent0 = torch.randn(1, T, N, Din, generator=g)
     context = torch.randn(1, T, S, Dc, generator=g).to(dev)
     mask = torch.zeros(1, T); mask[0, 0] = 1.0
     framestep = torch.arange(T, dtype=torch.float32)[None]
     total = args.warmup + args.steps
-    # `value` is measured with every algorithmic operation executed (exact_shortcuts=False); the product default - two exact,
-    # bit-identical shortcuts of the CFG batch (include/actionmesh_amd.h am_set_branch_hints) - is timed behind it and reported
-    # next to it as `with_exact_shortcuts`, never as `value`
-    sched = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=False)
     cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            barrier()
-            torch.cuda.synchronize(dev)
-
+    cfg_groups = 2 if (args.cfg_parallel and world % 2 == 0) else 1
     # N > 1: the sampler keeps the latents sharded by frames across the steps, as HipSchedulerFlow.denoise does (no velocity gather
     # per step; --gather-every-step restores it for A/B); the frames are gathered once, outside the timed region, for the fingerprint
     local_latents = world > 1 and not args.gather_every_step
-    loop = sched._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
-                                   framestep=framestep, local_latents=local_latents)
-    for _ in range(args.warmup):
-        next(loop)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        next(loop)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        elapsed = max_over_ranks(elapsed)
-    model.check_exchange(block=True)
-    if local_latents:
-        model.gather_latent_frames(init_latent[0], 2)
-    assert bool(torch.isfinite(init_latent).all()), "non-finite latents"
-    # what the sampler has made of the latents after warmup + steps steps: every rank holds the full tensor (like the reference), so a
-    # 1-rank and an N-rank run of the same command must agree to the sharding tolerance (tests/test_multi_gpu.py compares them)
-    fp_lat = init_latent[0, 1:].double()
-    fingerprint = {"after_steps": total, "rms": float(fp_lat.pow(2).mean().sqrt()), "mean": float(fp_lat.mean()),
-                   "sample": [round(float(x), 6) for x in init_latent[0, -1, ::max(1, N // 8), 0].double().cpu()[:8]]}
-    sched2 = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=True)
-    loop2 = sched2._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev), framestep=framestep,
-                                     local_latents=local_latents)
-    next(loop2)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        next(loop2)
-    sync()
-    elapsed2 = time.perf_counter() - t0
-    if world > 1:
-        elapsed2 = max_over_ranks(elapsed2)
-    model.check_exchange(block=True)
 
-    step_flops = model._engine.step_flops(2, T, N, S)
-    steps_per_s = args.steps / elapsed
-    # the arithmetic type the inflated self-attention REALLY ran in (am_attention_counters), not the one that was asked for
-    n_fp8, n_bf16 = model._engine.attention_counters()
-    ran = "fp8" if (n_fp8 > 0 and n_bf16 == 0) else "bf16" if n_fp8 == 0 else f"mixed (fp8 x{n_fp8}, bf16 x{n_bf16})"
-    if ran != ("fp8" if args.dtype.startswith("fp8") else args.dtype):
-        raise SystemExit(f"bench.py: --dtype {args.dtype} was requested but the engine's self-attention ran in {ran}")
-    result = {
-        "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
-        "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": ran, "data": "synthetic",
-        "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
-                               f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
-                               "random-init weights, seeded N(0,1) latents/context resident in HBM"
-                               + ("; self-attention in fp8 e4m3 (everything else bf16)" if ran == "fp8" else ""),
-                   "parallelism": ("single GPU" if world == 1 else
-                                   f"cfg-branch x{2 if world % 2 == 0 else 1} * frame-shard x{world // (2 if world % 2 == 0 else 1)}"),
-                   "step_flops": step_flops},
-        "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
-        "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if ran == "fp8" else PEAK_BF16_TFLOPS), 4),
-        "attention_launches": {"fp8": n_fp8, "bf16": n_bf16},
-        "attention_probabilities": ("exponent-field e4m3 bytes, p = 2^n (1 + f) (fp8_fast: no transcendental instruction)" if args.dtype == "fp8_fast"
-                                    else "exp2, rounded to e4m3" if ran == "fp8" else "exp2, rounded to bf16"),
-        # second half of BASELINE.json's metric: needs the pretrained checkpoints (facebook/ActionMesh, TripoSG, RMBG) and a
-        # real video, none reachable offline - not measured here, and nothing in `value` stands in for it
-        "with_exact_shortcuts": {"ms_per_step": round(elapsed2 / args.steps * 1e3, 2), "value": round(args.steps / elapsed2, 4),
-                                 "what": "the product default: the unconditional CFG branch's cross-attention is its to_out bias "
-                                         "(zero context), layer 0's self-attention branch is computed once for both branches "
-                                         "(identical inputs) - bit-identical latents (tests/test_denoiser_gpu.py::"
-                                         "test_exact_shortcuts_are_bit_identical); `value` above executes every operation"},
-        "hip_graph": bool(args.graph and world == 1),
-        "latents_fingerprint": fingerprint,
-        "latents_sharded_across_steps": bool(local_latents),
-        "end_to_end_video_to_4d_s": None,
-        "end_to_end_note": "unmeasured: pretrained weights / assets unreachable offline; the GPU stages chained on synthetic "
-                           "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
-    }
-    if rank == 0 and not args.no_roofline:
-        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=args.dtype)
-    if rank == 0 and world == 1:
+    def sync(collective=True):
+        torch.cuda.synchronize(dev)
+        if world > 1 and collective:
+            barrier()
+            torch.cuda.synchronize(dev)
+
+    def run_leg(exchange, group):
+        """warmup + `steps` timed steps of the sampler on a fresh HipDenoiser (process group `group`, exchange back-end `exchange`), then
+        the same with the product's exact shortcuts.  Returns the timings, the final latents (host) and the engine's own counters."""
+        coll = group is not None                    # rank 0's single-rank re-run (group None) must not enter a collective
+        if exchange is not None:
+            os.environ["ACTIONMESH_AMD_EXCHANGE"] = exchange
+        if exchange == "rccl" and args.same_device:
+            raise RuntimeError("RCCL refuses two ranks on one device (--same-device): this leg cannot run here")
+        model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, attn_dtype=args.dtype,
+                            cfg_parallel=bool(args.cfg_parallel), **hp)
+        model.load_state_dict(sd)
+        model.to(dev).eval()
+        init_latent = init_latent0.clone().to(dev)
+        # `value` is measured with every algorithmic operation executed (exact_shortcuts=False); the product default - two exact,
+        # bit-identical shortcuts of the CFG batch (include/actionmesh_amd.h am_set_branch_hints) - is timed behind it and reported
+        # next to it as `with_exact_shortcuts`, never as `value`
+        sched = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=False)
+        loop = sched._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev),
+                                       framestep=framestep, local_latents=local_latents and group is not None)
+        for _ in range(args.warmup):
+            next(loop)
+        sync(coll)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            next(loop)
+        sync(coll)
+        elapsed = time.perf_counter() - t0
+        if world > 1 and group is not None:
+            elapsed = max_over_ranks(elapsed)
+        model.check_exchange(block=True)
+        if local_latents and group is not None:
+            model.gather_latent_frames(init_latent[0], 2)
+        assert bool(torch.isfinite(init_latent).all()), "non-finite latents"
+        final = init_latent.detach().float().cpu().clone()
+        sched2 = HipSchedulerFlow(num_inference_steps=max(50, total), shift=3.0, is_additive=True, exact_shortcuts=True)
+        loop2 = sched2._flow_sample_impl(model, cfgd, init_latent, context, device=dev, mask=mask.to(dev), framestep=framestep,
+                                         local_latents=local_latents and group is not None)
+        next(loop2)
+        sync(coll)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            next(loop2)
+        sync(coll)
+        elapsed2 = time.perf_counter() - t0
+        if world > 1 and group is not None:
+            elapsed2 = max_over_ranks(elapsed2)
+        model.check_exchange(block=True)
+        n_fp8, n_bf16 = model._engine.attention_counters()
+        ex = getattr(model._engine, "exchange", None)
+        out = {"elapsed": elapsed, "elapsed2": elapsed2, "final": final, "step_flops": model._engine.step_flops(2, T, N, S),
+               "n_fp8": n_fp8, "n_bf16": n_bf16, "flags_fine_grained": getattr(ex, "flags_fine_grained", None)}
+        model._engine.close()
         del model
+        torch.cuda.empty_cache()
+        return out
+
+    def fingerprint_of(final):
+        # what the sampler has made of the latents after warmup + steps steps: every rank holds the full tensor (like the reference)
+        fp_lat = final[0, 1:].double()
+        return {"after_steps": total, "rms": float(fp_lat.pow(2).mean().sqrt()), "mean": float(fp_lat.mean()),
+                "sample": [round(float(x), 6) for x in final[0, -1, ::max(1, N // 8), 0].double()[:8]]}
+
+    def build_result(legs, exchange_ab, fingerprint_check):
+        best = min(legs.values(), key=lambda r: r["elapsed"]) if legs else None
+        return _result(best, legs, exchange_ab, fingerprint_check)
+
+    def _result(best, legs, exchange_ab, fingerprint_check):
+        elapsed, elapsed2, step_flops = best["elapsed"], best["elapsed2"], best["step_flops"]
+        steps_per_s = args.steps / elapsed
+        # the arithmetic type the inflated self-attention REALLY ran in (am_attention_counters), not the one that was asked for
+        n_fp8, n_bf16 = best["n_fp8"], best["n_bf16"]
+        ran = "fp8" if (n_fp8 > 0 and n_bf16 == 0) else "bf16" if n_fp8 == 0 else f"mixed (fp8 x{n_fp8}, bf16 x{n_bf16})"
+        if ran != ("fp8" if args.dtype.startswith("fp8") else args.dtype):
+            raise SystemExit(f"bench.py: --dtype {args.dtype} was requested but the engine's self-attention ran in {ran}")
+        result = {
+            "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": round(steps_per_s, 4),
+            "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": ran, "data": "synthetic",
+            "config": {"workload": f"{args.shape}: Stage-I denoise step, B=2 (CFG) x T={T} frames x N={N} tokens, "
+                                   f"width {C} ({H} heads x 128), {NL} layers all inflated, S={S} ctx tokens, "
+                                   "random-init weights, seeded N(0,1) latents/context resident in HBM"
+                                   + ("; self-attention in fp8 e4m3 (everything else bf16)" if ran == "fp8" else ""),
+                       "parallelism": ("single GPU" if world == 1 else f"cfg-branch x{cfg_groups} * frame-shard x{world // cfg_groups}"),
+                       "step_flops": step_flops},
+            "step_tflops_per_gpu": round(step_flops * steps_per_s / world / 1e12, 1),
+            "step_frac_of_bf16_peak": round(step_flops * steps_per_s / world / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "step_frac_of_dtype_peak": round(step_flops * steps_per_s / world / 1e12 / (PEAK_FP8_TFLOPS if ran == "fp8" else PEAK_BF16_TFLOPS), 4),
+            "attention_launches": {"fp8": n_fp8, "bf16": n_bf16},
+            "attention_probabilities": ("exponent-field e4m3 bytes, p = 2^n (1 + f) (fp8_fast: no transcendental instruction)" if args.dtype == "fp8_fast"
+                                        else "exp2, rounded to e4m3" if ran == "fp8" else "exp2, rounded to bf16"),
+            # second half of BASELINE.json's metric: needs the pretrained checkpoints (facebook/ActionMesh, TripoSG, RMBG) and a
+            # real video, none reachable offline - not measured here, and nothing in `value` stands in for it
+            "with_exact_shortcuts": {"ms_per_step": round(elapsed2 / args.steps * 1e3, 2), "value": round(args.steps / elapsed2, 4),
+                                     "what": "the product default: the unconditional CFG branch's cross-attention is its to_out bias "
+                                             "(zero context), layer 0's self-attention branch is computed once for both branches "
+                                             "(identical inputs) - bit-identical latents (tests/test_denoiser_gpu.py::"
+                                             "test_exact_shortcuts_are_bit_identical); `value` above executes every operation"},
+            "hip_graph": bool(args.graph and world == 1),
+            "latents_fingerprint": fingerprint_of(best["final"]),
+            "latents_sharded_across_steps": bool(local_latents),
+            "end_to_end_video_to_4d_s": None,
+            "end_to_end_note": "unmeasured: pretrained weights / assets unreachable offline; the GPU stages chained on synthetic "
+                               "weights are timed by tools/e2e_synthetic.py (profiles/), which is not this metric",
+        }
+        if args.same_device:
+            result["same_device_dry_run"] = True
+            result["metric"] = "DRY RUN (all ranks on ONE device, gloo control plane, copy-engine exchange) of: " + result["metric"]
+        if world > 1:
+            name = next(k for k, v in legs.items() if v is best)
+            result["exchange_backend"] = ("peer (copy engines, IPC-mapped gather buffers)" if name == "peer" else "rccl")
+            result["exchange_ab"] = exchange_ab
+            result["fingerprint_check"] = fingerprint_check
+            result["fingerprint_ok"] = None if fingerprint_check is None else bool(fingerprint_check["ok"])
+        return result
+
+    # ---- the legs -------------------------------------------------------------------------------------------------------------------
+    exchange_ab, legs = None, {}
+    if world == 1:
+        best = run_leg(None, None)
+    else:
+        want = os.environ.get("ACTIONMESH_AMD_EXCHANGE") or args.exchange or ("peer" if args.same_device else "ab")
+        # rccl first: torch.distributed's bread-and-butter collective is the leg least likely to hang on first contact with a real node;
+        # the copy-engine leg (custom IPC + flag protocol, bounded waits) then runs under the watchdog
+        order = ["rccl", "peer"] if want == "ab" else [want]
+        from actionmesh_amd.sharding import run_exchange_legs
+        state = {"printed": False}
+
+        def on_watchdog(leg, legs_so_far, report):
+            # a later leg hung (a collective that never returns cannot be caught): report the completed leg(s) and leave
+            report[leg] = {"ok": False, "error": f"no result after {args.leg_timeout:.0f} s (watchdog); the line reports the other leg"}
+            if rank == 0 and not state["printed"] and legs_so_far:
+                state["printed"] = True
+                print(json.dumps(build_result(legs_so_far, report, fingerprint_check=None)), flush=True)
+            os._exit(0 if legs_so_far else 3)
+
+        def leg(name):
+            # peer: the model's own small collectives (velocity gather among same-frame ranks, the final frame gather) ride on gloo,
+            # so the leg makes no RCCL call at all; rccl: everything on the nccl WORLD
+            r = run_leg(name, ctl if name == "peer" else dist.group.WORLD)
+            torch.cuda.synchronize(dev)
+            return r
+
+        def describe(r):
+            d = {"ms_per_step": round(r["elapsed"] / args.steps * 1e3, 2),
+                 "with_exact_shortcuts_ms_per_step": round(r["elapsed2"] / args.steps * 1e3, 2)}
+            if r.get("flags_fine_grained") is not None:
+                d["flags_fine_grained"] = bool(r["flags_fine_grained"])
+            return d
+
+        legs, exchange_ab = run_exchange_legs(order, leg, ctl, rank, args.leg_timeout, on_watchdog, describe)
+        if not legs:
+            raise SystemExit(f"bench.py: every exchange leg failed: {exchange_ab}")
+        best = min(legs.values(), key=lambda r: r["elapsed"])
+
+    # ---- N > 1: is the sharded result the single-rank result?  Rank 0 re-runs the SAME warmup + steps steps on an unsharded engine (its
+    # own device, outside every timed region) and compares the final latents of every completed leg with it: a wrong-but-finite sharded
+    # run must not be published as a scaling point (VERDICT r04 weak #5c).  Stated tolerance 3e-2 rel-L2: two bf16 executions with
+    # different reduction orders decorrelate step by step (one forward: <= 8e-3, tests/test_denoiser_gpu.py), both stay ~1e-2 of fp32.
+    fingerprint_check = None
+    if world > 1 and not args.no_fingerprint_check:
+        if rank == 0:
+            try:
+                single = run_leg(None, None)
+                ref = single["final"]
+                fingerprint_check = {"tol_rel_l2": 3e-2, "single_rank_fingerprint": fingerprint_of(ref), "legs": {}}
+                for k, r in legs.items():
+                    d = float((r["final"].double() - ref.double())[0, 1:].norm() / ref.double()[0, 1:].norm())
+                    fingerprint_check["legs"][k] = round(d, 6)
+                fingerprint_check["ok"] = all(v <= 3e-2 for v in fingerprint_check["legs"].values())
+                fingerprint_check["single_rank_ms_per_step"] = round(single["elapsed"] / args.steps * 1e3, 2)
+            except Exception as e:                       # noqa: BLE001
+                fingerprint_check = {"ok": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+        barrier()
+
+    result = _result(best, legs if world > 1 else {"single": best}, exchange_ab, fingerprint_check)
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = attention_roofline(T, N, H, dev, world, dtype=args.dtype, groups=cfg_groups)
+    if rank == 0 and world == 1:
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.shape == "headline" and not args.no_nominal:
         result["nominal"] = nominal_record(dev, args.dtype)             # SURVEY 8(d): the shipped architecture next to the headline
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(hp, sd, step_flops, S, T, N, deep=args.cpu_baseline_deep, shape=args.shape)
-    if args.same_device:
-        result["same_device_dry_run"] = True
-        result["metric"] = "DRY RUN (all ranks on ONE device, gloo control plane, copy-engine exchange) of: " + result["metric"]
-        result["exchange_backend"] = "peer (copy engines, IPC-mapped gather buffers)"
-    elif world > 1:
-        result["exchange_backend"] = os.environ.get("ACTIONMESH_AMD_EXCHANGE", "rccl")
+        result["cpu_baseline"] = cpu_baseline(hp, sd, best["step_flops"], S, T, N, deep=args.cpu_baseline_deep, shape=args.shape)
     if world > 1:
         barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
+        if fingerprint_check is not None and not fingerprint_check["ok"]:
+            print(f"bench.py: the sharded latents differ from the single-rank run beyond the stated tolerance: {fingerprint_check}", file=sys.stderr, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -298,6 +298,10 @@ int am_attention_fp8(const am_attn_args* args, const uint8_t* q8, const uint8_t*
  *   am_peer_signal            *flag = value (system-scope release) after everything earlier on `stream`
  *   am_peer_wait              holds `stream` until (int32)(*flag - value) >= 0; gives up after ~20 s and sets *fault_word */
 int am_peer_alloc(size_t bytes, void** dev_ptr);
+/* The flag block of an exchange (polled by a kernel of the owning device while a PEER device writes it): device-local FINE-GRAINED
+ * memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained)), zeroed, IPC-exportable like am_peer_alloc's; *fine_grained = 1, or 0
+ * when the runtime refused and an ordinary allocation was returned instead.  Free with am_peer_free. */
+int am_peer_alloc_flags(size_t bytes, void** dev_ptr, int* fine_grained);
 int am_peer_free(void* dev_ptr);
 int am_peer_export(void* dev_ptr, uint8_t* handle64);
 int am_peer_open(const uint8_t* handle64, void** dev_ptr);

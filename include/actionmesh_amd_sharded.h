@@ -29,6 +29,10 @@ typedef struct {
   void* peer_flags[AM_PEER_MAX_RANKS];
   void* side_stream;
   uint32_t seq;
+  /* owned by the ring: two hipEvent_t (fork: compute -> side stream; pushed: side -> compute), created by the first
+   * am_forward_sharded_peer on the ring's device, destroyed by am_peer_ring_destroy.  Zero-initialise. */
+  void* ev_fork;
+  void* ev_pushed;
 } am_peer_ring;
 
 /* The whole sharded forward of this rank: begin; per layer pre-attention, then for an inflated layer the exchange - pushes of the
@@ -39,6 +43,9 @@ typedef struct {
  * created with world_size = ring->world > 1 and bound to ring->kv (am_bind_kv_buffers / am_bind_kv8_buffers). */
 int am_forward_sharded_peer(am_handle h, const float* x_dev, const float* t_bt_host, int B, int T_local, int N, uint16_t* v_out,
                             am_peer_ring* ring, const uint8_t* inflated, int num_layers, void* stream);
+
+/* Destroys the events the ring owns (before its buffers are freed / the struct is dropped).  The ring may be used again afterwards. */
+int am_peer_ring_destroy(am_peer_ring* ring);
 
 #ifdef __cplusplus
 }

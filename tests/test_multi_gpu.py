@@ -147,3 +147,31 @@ def test_bench_world_gt_1_branch_runs_on_one_device(dtype):
         tol = 5e-2 if dtype == "fp8" else 2e-2          # the sharding tolerance of tools/peer_selftest.py, on O(1) latents
         assert abs(fp["rms"] - fp1["rms"]) < tol * fp1["rms"], (fp, fp1)
         assert max(abs(a - b) for a, b in zip(fp["sample"], fp1["sample"])) < tol * max(1.0, fp1["rms"]), (fp, fp1)
+        # round 5: the line checks ITSELF - rank 0 re-ran the same steps on an unsharded engine and compared the final latents
+        assert d["fingerprint_ok"] is True and d["fingerprint_check"]["legs"]["peer"] <= 3e-2, d["fingerprint_check"]
+        assert d["exchange_ab"]["peer"]["ok"] is True and d["exchange_ab"]["peer"]["ms_per_step"] > 0
+        if world == 4:
+            assert isinstance(d["exchange_ab"]["peer"]["flags_fine_grained"], bool)
+
+
+def test_bench_exchange_ab_falls_back_when_one_backend_fails():
+    """`--exchange ab` (the default of a real multi-GPU launch) with every rank on ONE device: the RCCL leg cannot run here and raises -
+    the line must still come out, carry the copy-engine leg as `value`, and say what happened to the other one (VERDICT r04 next #2:
+    "falling back rather than dying if one fails")."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _bench(4, ("--exchange", "ab"))
+    ab = d["exchange_ab"]
+    assert ab["rccl"]["ok"] is False and "RCCL refuses two ranks" in ab["rccl"]["error"]
+    assert ab["peer"]["ok"] is True and d["exchange_backend"].startswith("peer") and d["value"] > 0
+    assert d["fingerprint_ok"] is True
+
+
+def test_bench_pure_frame_sharding():
+    """`--cfg-parallel 0`: north_star's partition - every rank computes BOTH guidance branches of T / N frames (4 ranks x 1 frame of
+    the 4-frame plumbing shape), one K/V exchange per layer among all ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _bench(4, ("--cfg-parallel", "0"))
+    assert d["config"]["parallelism"] == "cfg-branch x1 * frame-shard x4"
+    assert d["fingerprint_ok"] is True and d["exchange_ab"]["peer"]["ok"] is True

@@ -373,3 +373,65 @@ def test_sampler_keeps_latents_sharded_across_steps(world, cfg_parallel, split):
         per_forward_kv = 2 * layers_inflated                     # K and V^T shards, one all-gather each per inflated layer
         forwards = steps * (2 if split else 1)
         assert got[0][3][0][0] == forwards * per_forward_kv + 1, got[0][3]
+
+
+# ---- bench.py --gpus N: both exchange back-ends in one invocation, fallback, watchdog ------------------------
+def _legs_worker(rank, world, port, outdir, scenario):
+    import json
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from actionmesh_amd.sharding import run_exchange_legs
+    ctl = dist.new_group(backend="gloo")
+
+    def write(payload):
+        with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+            json.dump(payload, f)
+
+    def run_leg(name):
+        if scenario == "rccl_raises_on_rank1" and name == "rccl" and rank == 1:
+            raise RuntimeError("ncclSystemError: stand-in failure")
+        if scenario == "second_leg_hangs" and name == "peer":
+            time.sleep(600)                               # a collective that never returns
+        return {"elapsed": 1.0 + (0.5 if name == "rccl" else 0.0) + 0.01 * rank}
+
+    def on_watchdog(name, legs, report):
+        report[name] = {"ok": False, "error": "watchdog"}
+        write({"watchdog": name, "legs": sorted(legs), "report": report})
+        os._exit(0)
+
+    legs, report = run_exchange_legs(["rccl", "peer"], run_leg, ctl, rank, 3.0, on_watchdog,
+                                     describe=lambda r: {"ms_per_step": r["elapsed"] * 1e3})
+    write({"legs": sorted(legs), "report": report})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["both_ok", "rccl_raises_on_rank1", "second_leg_hangs"])
+def test_exchange_ab_fallback_and_watchdog(tmp_path, scenario):
+    """sharding.run_exchange_legs between two gloo processes with stand-in legs: (a) both complete - both reported; (b) the RCCL leg
+    raises on ONE rank - every rank agrees it failed (error text where it happened, "failed on another rank" elsewhere) and the
+    copy-engine leg runs and is the result; (c) the second leg never returns - the watchdog of every rank reports the first leg and
+    leaves with exit code 0."""
+    import json
+    ctxm = mp.get_context("spawn")
+    port = 29400 + (os.getpid() * 11 + len(scenario) * 17) % 500
+    procs = [ctxm.Process(target=_legs_worker, args=(r, 2, port, str(tmp_path), scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, p.exitcode
+    out = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    if scenario == "both_ok":
+        for o in out:
+            assert o["legs"] == ["peer", "rccl"] and o["report"]["rccl"]["ok"] and o["report"]["peer"]["ok"]
+            assert o["report"]["rccl"]["ms_per_step"] > o["report"]["peer"]["ms_per_step"]
+    elif scenario == "rccl_raises_on_rank1":
+        for o in out:
+            assert o["legs"] == ["peer"] and o["report"]["peer"]["ok"] and not o["report"]["rccl"]["ok"]
+        assert "failed on another rank" in out[0]["report"]["rccl"]["error"]
+        assert "stand-in failure" in out[1]["report"]["rccl"]["error"]
+    else:
+        for o in out:
+            assert o["watchdog"] == "peer" and o["legs"] == ["rccl"] and o["report"]["rccl"]["ok"] and not o["report"]["peer"]["ok"]

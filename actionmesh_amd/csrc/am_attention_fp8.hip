@@ -1194,7 +1194,11 @@ __global__ __launch_bounds__(512, 2) void attn_fp8p_kernel(f8_args p, unsigned l
   };
   auto ones_frag = [&]() __attribute__((always_inline)) {
     if ((ABL & 32) && in_loop) return stale;
-    const unsigned char* q = smem + P_LDS_ONES + lane * 32;
+    // every byte of the block is e4m3 1.0, so every lane reads the SAME 32 bytes: a broadcast, which the LDS serves without a bank
+    // conflict.  Round 4 read lane * 32 - a 32-byte lane stride, lanes i and i + 8 of every 16-lane group on the same banks: two of
+    // the 18 fragment reads of a tile two-way conflicted = the 10 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE the r04 PMC pass
+    // showed where the bf16 kernel has ~0
+    const unsigned char* q = smem + P_LDS_ONES;
     const u32x4_t a = *reinterpret_cast<const u32x4_t*>(q);
     const u32x4_t b = *reinterpret_cast<const u32x4_t*>(q + 16);
     return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};

@@ -249,6 +249,10 @@ int prepare_folds(am_model* m, hipStream_t st) {
     AM_TRY(am_ln_fold_weight(l.w_xq, l.ln_x_w, l.ln_x_b, nullptr, l.wf_xq, l.cs_xq, l.d_xq, C, C, st));
     AM_TRY(am_ln_fold_weight(l.w_ff1, l.ln_f_w, l.ln_f_b, l.b_ff1, l.wf_ff1, l.cs_ff1, l.d_ff1, F, C, st));
   }
+  // once per weight load, never inside a capture: the folded weights are read by every later forward on WHATEVER stream it is
+  // launched on (an eager forward on another torch stream, the graph stream after an eager call) - make them visible to all of
+  // them before the flag says so (they used to be ordered only with the stream of the first forward)
+  AM_HIP(hipStreamSynchronize(st));
   m->folds_ready = true;
   return AM_OK;
 }

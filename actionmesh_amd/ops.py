@@ -72,7 +72,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
          a_map: Tuple[int, int, int] = (0, 0, 0), c_map: Tuple[int, int, int] = (0, 0, 0),
          M: Optional[int] = None, force_small: bool = False, legacy: bool = False,
          force_big: bool = False, ablate: int = 0,
-         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, ln_part: Optional[torch.Tensor] = None) -> torch.Tensor:
+         ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, ln_part: Optional[torch.Tensor] = None,
+         gelu_table: bool = True) -> torch.Tensor:
     """out = act(cat(a, a2) @ w.T + bias) + residual   (bf16, fp32 accumulate).
 
     a (Ma, K1), a2 (Ma, K2) optional, w (N, K1+K2), bias fp32 (N,), residual/out (Mc, N).
@@ -103,7 +104,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     g.M, g.N, g.K = M, N, K
     # 0x100: force the 128x128 register-staged kernel (the small-problem path; tests compare the two tilings);
     # 0x200: the round-1 lockstep main loop of the 256x256 tile (same-box A/B); 0x400: the 256x256 tile at any grid size (tests)
-    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0xF800)
+    # 0x10000: the arithmetic GELU epilogue in the 256x256 tile too (default: the bit-identical LDS table, am_gemm.hip GT_LO)
+    g.act = (1 if gelu else 0) | (0x100 if force_small else 0) | (0x200 if legacy else 0) | (0x400 if force_big else 0) | (ablate & 0xF800) \
+        | (0 if gelu_table else 0x10000)
     g.a_G, g.a_gs, g.a_off = a_map
     g.c_G, g.c_gs, g.c_off = c_map
     if ln is not None:

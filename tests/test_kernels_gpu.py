@@ -158,6 +158,37 @@ def test_gemm256_pingpong_main_loop(dev, M, N, K, mode):
     assert torch.equal(out, ops.gemm(a, w, force_big=True, **kw)), "run-to-run bits"
 
 
+@pytest.mark.parametrize("scale,ln", [(1.0, False), (3.5, False), (0.02, False), (1.0, True)])
+def test_gelu_table_is_bit_identical(dev, scale, ln):
+    """Round 5: the 256x256 tile evaluates F.gelu by a 10 KiB LDS table of f2bf(gelu_erf(x)) over the bf16 values with 2^-17 <= |x| < 8
+    (am_gemm.hip GT_LO) instead of ~28 VALU slots per element; values outside take the arithmetic form.  Same bits as the arithmetic
+    epilogue (gelu_table=False) on: unit-scale pre-activations, wide ones (|x| >= 8 in ~2 % of the entries), tiny ones, exact zeros
+    (zero rows x zero bias), -0.0 / huge / NaN-free extremes planted through the bias, and under a folded LayerNorm."""
+    from actionmesh_amd import ops
+    M, N, K = 2048 + 256, 1024, 512
+    a = _randn((M, K), 11, dev, scale).to(torch.bfloat16)
+    a[5] = 0                                                    # exact-zero rows
+    a[300:310] = 0
+    w = _randn((N, K), 12, dev, K ** -0.5).to(torch.bfloat16)
+    bias = _randn((N,), 13, dev, 0.5 * scale)
+    bias[:8] = torch.tensor([0.0, -0.0, 9.0, -9.0, 300.0, -300.0, 1e-6, -1e-6], device=dev)
+    kw = {}
+    if ln:
+        gamma = torch.rand(K, device=dev) + 0.5
+        beta = torch.randn(K, device=dev) * 0.2
+        wf, colsum, d = ops.ln_fold_weight(w, gamma, beta, bias)
+        w, bias, kw = wf, d, dict(ln=(ops.row_stats(a), colsum))
+    tab = ops.gemm(a, w, bias=bias, gelu=True, force_big=True, **kw)
+    ari = ops.gemm(a, w, bias=bias, gelu=True, force_big=True, gelu_table=False, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(tab.view(torch.int16), ari.view(torch.int16)), f"{int((tab.view(torch.int16) != ari.view(torch.int16)).sum())} elements differ"
+    pre = ops.gemm(a, w, bias=bias, force_big=True, **kw).float()
+    frac_out = float(((pre.abs() >= 8) | (pre.abs() < 2.0 ** -17)).float().mean())
+    print(f"gelu table scale {scale} ln {ln}: {frac_out:.2e} of the pre-activations outside the table")
+    ref = torch.nn.functional.gelu(pre)
+    assert float((tab.float() - ref).abs().max()) <= 2.0 ** -8 * max(1.0, float(ref.abs().max()))
+
+
 def test_gemm_in_place_residual(dev):
     from actionmesh_amd import ops
     M, N, K = 700, 256, 256

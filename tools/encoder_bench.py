@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"])
     a = ap.parse_args()
     from actionmesh_amd import image_encoder as IE
     dev = torch.device("cuda:0")
@@ -33,7 +34,7 @@ def main():
             sd[name] = 0.5 * torch.randn(shape, generator=g)
         else:
             sd[name] = torch.zeros(shape)
-    enc = IE.HipImageEncoder(state_dict=sd).to(dev)
+    enc = IE.HipImageEncoder(state_dict=sd, dtype=a.dtype).to(dev)
     pix = torch.randn((a.frames, 3, 224, 224), generator=g).to(dev)
     out = enc.encode_pixels(pix)
     torch.cuda.synchronize()
@@ -41,13 +42,13 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):
-        enc.encode_pixels(pix, out_dtype=torch.bfloat16)
+        enc.encode_pixels(pix, out_dtype=enc.dt16)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     fl = enc.step_flops(a.frames, 224, 224)
     print(json.dumps({"metric": "context-encoder calls/sec (16 frames x 224x224, DINOv2 ViT-L/14)", "value": round(1e3 / ms, 2),
-                      "unit": "calls/s", "ms_per_call": round(ms, 3), "n_gpus": 1, "dtype": "bf16", "data": "synthetic",
+                      "unit": "calls/s", "ms_per_call": round(ms, 3), "n_gpus": 1, "dtype": "bf16" if a.dtype == "bfloat16" else "f16", "data": "synthetic",
                       "algorithmic_flops": fl, "tflops": round(fl / ms / 1e9, 1),
                       "frac_of_bf16_peak": round(fl / ms / 1e9 / 2500.0, 4),
                       "config": {"workload": f"T={a.frames} 224x224 patch 14 width 1024 heads 16x64 layers 24"}}))

@@ -148,7 +148,13 @@ def leg(name, fn, seconds, tel, flops=None):
                 d = [(b - a) / dacc for a, b in zip(first[k], last[k])]
                 rec[k.split(".")[1].replace("_acc", "_share_per_xcd")] = [round(x, 3) for x in d]
     if "energy_accumulator" in first and "energy_accumulator" in last and last["t"] > first["t"]:
-        rec["energy_accumulator_w"] = round((last["energy_accumulator"] - first["energy_accumulator"]) * 15.259e-6 / (last["t"] - first["t"]), 1)
+        # the firmware's energy accumulator (15.259 uJ units) over the leg: average socket power, and - round 5 - JOULES PER LAUNCH,
+        # the quantity a power-capped kernel is really priced in (time = energy / cap): total, and per algorithmic flop
+        joules = (last["energy_accumulator"] - first["energy_accumulator"]) * 15.259e-6
+        rec["energy_accumulator_w"] = round(joules / (last["t"] - first["t"]), 1)
+        rec["joules_per_launch"] = round(rec["energy_accumulator_w"] * ms * 1e-3, 4)
+        if flops:
+            rec["pj_per_flop"] = round(rec["energy_accumulator_w"] * ms * 1e-3 / flops * 1e12, 4)
     if viol is not None:
         rec["violation_status_under_load"] = viol
     short = {k: rec[k] for k in rec if k not in ("violation_status_under_load",)}
@@ -156,11 +162,69 @@ def leg(name, fn, seconds, tel, flops=None):
     return rec, s.rows
 
 
+def energy_table(a, tel):
+    """Round 5: the bf16 attention as an ENERGY problem.  The same launch at the headline shape on N(0,1) operands,
+    product form and the timing ablations of an -DAM_ATTN_ABLATIONS build (ACTIONMESH_AMD_LIB=build/variants/libam_abl.so), each with its
+    time, average socket power, joules per launch and pJ per algorithmic flop; the differences between rows price the pieces:
+    product - (no softmax) = the softmax VALU; (no softmax) - (no softmax, no LDS reads) = the fragment reads; the pure MFMA + DMA
+    stream is the floor the schedule sits on.  Also: the fp8 forms and the ff1 GEMM with / without the GELU table."""
+    dev = torch.device("cuda:0")
+    T, N, C, H = 16, 4096, 1024, 8
+    B, L = 2, N + 1
+    Sq = T * L
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randn(s, device=dev, generator=g).to(torch.bfloat16)
+    Q = rnd(B, H, ops.round_up(Sq, 256), 128); K = rnd(B, H, ops.round_up(Sq, 64), 128); Vt = rnd(B, H, 128, ops.round_up(Sq, 64))
+    out = torch.empty((B * Sq, C), dtype=torch.bfloat16, device=dev)
+    fl = 4.0 * Sq * Sq * C * B
+    have_abl = True
+    try:
+        ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=3008)
+        torch.cuda.synchronize()
+    except RuntimeError:
+        have_abl = False
+    ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out); qz = ops.attention_fp8.last_quantized
+    R = B * Sq
+    A = rnd(R, C); W1 = rnd(4 * C, C) * 0.03; b1 = torch.zeros(4 * C, device=dev); Cc = torch.empty((R, 4 * C), dtype=torch.bfloat16, device=dev)
+    legs = [("idle (sleep)", lambda: time.sleep(0.01), None, 1.5),
+            ("attention bf16 product (lazy re-base)", lambda: ops.attention(Q, K, Vt, Sq, Sq, out=out), fl, a.seconds)]
+    if have_abl:
+        for code, what in ((3001, "no exp (x0.5 instead)"), (3002, "no row max"), (3004, "no tile barrier / DMA drain"),
+                           (3008, "no softmax at all (MFMA + LDS fragment reads + DMA)"), (3016, "no LDS fragment reads (stale registers)"),
+                           (3030, "pure MFMA stream (no softmax, no reads, no barrier, no row max)")):
+            legs.append((f"attention bf16 ablation {code}: {what}", lambda c=code: ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=c), fl, a.seconds))
+    legs += [("attention fp8 (attend only)", lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz), fl, a.seconds),
+             ("attention fp8_fast (attend only)", lambda: ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out, quantized=qz, ablate=400), fl, a.seconds),
+             ("GEMM ff1 + GELU (table) 131104 x 4096 x 1024", lambda: ops.gemm(A, W1, bias=b1, gelu=True, out=Cc), 2.0 * R * C * 4 * C, a.seconds),
+             ("GEMM ff1 + GELU (arithmetic)", lambda: ops.gemm(A, W1, bias=b1, gelu=True, out=Cc, gelu_table=False), 2.0 * R * C * 4 * C, a.seconds),
+             ("GEMM ff1, no activation", lambda: ops.gemm(A, W1, bias=b1, out=Cc), 2.0 * R * C * 4 * C, a.seconds)]
+    log = {"what": "energy per launch, headline shape, N(0,1) operands", "ablation_build": have_abl, "legs": []}
+    idle_w = None
+    for name, fn, flops, sec in legs:
+        rec, _rows = leg(name, fn, sec, tel, flops)
+        if flops is None:
+            idle_w = rec.get("energy_accumulator_w")
+        elif idle_w is not None and "energy_accumulator_w" in rec:
+            rec["joules_per_launch_above_idle"] = round((rec["energy_accumulator_w"] - idle_w) * rec["ms_per_launch"] * 1e-3, 4)
+        log["legs"].append(rec)
+    print("\n%-78s %9s %8s %9s %9s %8s" % ("leg", "ms", "W", "J/launch", "J>idle", "pJ/flop"))
+    for r in log["legs"]:
+        print("%-78s %9.3f %8.1f %9.3f %9s %8s" % (r["leg"][:78], r["ms_per_launch"], r.get("energy_accumulator_w", float("nan")),
+                                                  r.get("joules_per_launch", float("nan")), r.get("joules_per_launch_above_idle", "-"),
+                                                  r.get("pj_per_flop", "-")))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(log, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--energy-table", action="store_true", help="per-variant joules per launch (see energy_table)")
     a = ap.parse_args()
+    if a.energy_table:
+        return energy_table(a, Telemetry())
     tel = Telemetry()
     dev = torch.device("cuda:0")
     log = {"gpu_metrics_header": tel.header(), "power_cap": {k: (v if num(v) is not None else str(v)) for k, v in tel.power_cap().items()},

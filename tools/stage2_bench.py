@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--tokens", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=16)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float16"], help="the 16-bit type (round 5: float16 = libactionmesh_amd_f16.so)")
     a = ap.parse_args()
     from actionmesh_amd.autoencoder import HipAutoencoder
     from oracle.autoencoder_oracle import AEConfig, state_dict_spec      # shapes only (random weights below)
@@ -35,7 +36,7 @@ def main():
             sd[name] = torch.ones(shape)
         else:
             sd[name] = torch.zeros(shape)
-    m = HipAutoencoder(width=C, num_layers=a.layers, num_attention_heads=H)
+    m = HipAutoencoder(width=C, num_layers=a.layers, num_attention_heads=H, dtype=a.dtype)
     m.load_state_dict(sd)
     m.to(dev)
     T, N, V, To = a.frames, a.tokens, a.vertices, a.targets
@@ -56,7 +57,7 @@ def main():
     flops = To * (a.layers * per_layer + cross)
     print(json.dumps({"metric": "stage-II decode windows/sec (16f x 2048tok, 15 targets, 50k vertices)",
                       "value": round(1.0 / dt, 4), "unit": "windows/s", "seconds_per_window": round(dt, 3),
-                      "n_gpus": 1, "dtype": "bf16", "data": "synthetic", "algorithmic_flops": flops,
+                      "n_gpus": 1, "dtype": "bf16" if a.dtype == "bfloat16" else "f16", "data": "synthetic", "algorithmic_flops": flops,
                       "tflops": round(flops / dt / 1e12, 1), "frac_of_bf16_peak": round(flops / dt / 2.5e15, 4),
                       "config": {"workload": f"T={T} N={N} width={C} heads={H} layers={a.layers}+1 targets={To} vertices={V}"}}))
 

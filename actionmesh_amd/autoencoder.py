@@ -30,7 +30,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
-from . import _lib as L
+from . import _lib as _L
 from . import ops
 from ._lib import lib
 from .denoiser import rope_tables_host
@@ -53,7 +53,7 @@ class HipAutoencoder:
         self.query_dim = in_channels * (2 * embed_frequency + 1) + in_extra_channels
         self.query_pad = ops.round_up(self.query_dim, 64)
         self.device = torch.device("cpu")
-        self.dtype_pinned = None if dtype is None else L.kind_of(dtype)      # None: the caller's autocast dtype (compute_kind)
+        self.dtype_pinned = None if dtype is None else _L.kind_of(dtype)      # None: the caller's autocast dtype (compute_kind)
         self._sd: Optional[Dict[str, torch.Tensor]] = None
         self._w_kind: Dict[str, Dict[str, torch.Tensor]] = {}                 # "bf16" / "f16" -> device weights, uploaded on first use
         lib()      # fail loudly here if libactionmesh_amd.so is missing
@@ -84,7 +84,7 @@ class HipAutoencoder:
 
     def compute_kind(self) -> str:
         """'bf16' or 'f16' (HipDenoiser.compute_kind): the pinned dtype, else the autocast dtype of the calling region."""
-        return L.autocast_kind(self.dtype_pinned)
+        return _L.autocast_kind(self.dtype_pinned)
 
     @property
     def _w(self) -> Dict[str, torch.Tensor]:
@@ -92,7 +92,7 @@ class HipAutoencoder:
         if kind not in self._w_kind:
             if kind == "f16":
                 lib("f16")                                                   # fail loudly if the float16 build is missing
-            self._w_kind[kind] = self._upload(L.torch_dtype(kind))
+            self._w_kind[kind] = self._upload(_L.torch_dtype(kind))
         return self._w_kind[kind]
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
@@ -172,7 +172,7 @@ class HipAutoencoder:
             raise RuntimeError("HipAutoencoder: load_state_dict(...) and .to('cuda:N') first (there is no CPU path)")
         assert target_alphas.ndim == 2 and source_alpha.ndim == 1
         dev, C, w = self.device, self.width, self._w
-        dt16 = L.torch_dtype(self.compute_kind())
+        dt16 = _L.torch_dtype(self.compute_kind())
         B, T, N, D = latent.shape
         T_out, V, L = target_alphas.shape[1], query.shape[1], N + 1
         with torch.cuda.device(dev):

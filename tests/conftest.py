@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def host_threads(limit: int = 32) -> int:
+    """Thread count for the CPU oracle legs of the GPU tests: all cores up to `limit` - the GPU boxes have 128+ hardware threads and
+    torch's fp32 GEMMs get SLOWER when every one of them is used on the mid-sized matrices of these checks (bench.py probes the best
+    count for the same reason)."""
+    import torch
+    n = max(1, min(limit, os.cpu_count() or 1))
+    torch.set_num_threads(n)
+    return n

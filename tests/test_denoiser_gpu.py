@@ -407,7 +407,8 @@ def test_autoregressive_windows_configs2_at_the_headline_architecture(dev):
     bank.update(ts[0:1], anchor)
     W.generate_3d_latents(model, sched, cfgd, ts, context.to(dev), bank, anchor_idx=0, window=16, slide=15,
                           latent_shape=(N, D), seed=44, device=dev, noise_device="cpu")
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    from conftest import host_threads
+    host_threads()
     ref = WO.ListLatentBank((N, D))
     ref.update(ts[0:1], anchor)
     WO.generate_3d_latents(sd, cfg, ts, context, ref, 0, 16, 15, (N, D), steps, seed=44)

@@ -142,6 +142,9 @@ def main():
                                  ("ff2+res", C, F_, {"bias": True, "res": True}),
                                  ("skip(2C)", C, 2 * C, {"bias": True})):
             A = rnd(R, Kk); W = rnd(Nn, Kk); out = torch.empty((R, Nn), dtype=torch.bfloat16, device=dev)
+            if kw.get("gelu"):
+                W = (W.float() * Kk ** -0.5).to(torch.bfloat16)      # unit-variance pre-activations (a linear behind a LayerNorm): the
+                                                                     # GELU table's domain; N(0, 32^2) ones would all take its repair path
             bias = torch.randn(Nn, device=dev) if kw.get("bias") else None
             res = rnd(R, Nn) if kw.get("res") else None
             for small, leg, nm in ((False, False, "256sq-pingpong"), (False, True, "256sq-lockstep"), (True, False, "128sq-regstage")):
@@ -150,6 +153,10 @@ def main():
                 ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out,
                                              force_small=small, legacy=leg), a.reps)
                 print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
+            if kw.get("gelu"):     # round 5: the GELU epilogue by LDS table (product) vs arithmetic, and the same linear without the activation
+                for nm, k2 in (("256sq-pingpong, arithmetic GELU", dict(gelu=True, gelu_table=False)), ("256sq-pingpong, no activation", dict(gelu=False))):
+                    ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, out=out, **k2), a.reps)
+                    print(f"gemm {name:13s} M={R} N={Nn} K={Kk} {nm}: {ms:8.3f} ms  {2.0 * R * Nn * Kk / ms / 1e9:8.1f} TFLOP/s")
             if a.skew_gemm:
                 for units in (7, 1, 2, 3, 4, 6):
                     ms = timeit(lambda: ops.gemm(A, W, bias=bias, residual=res, gelu=kw.get("gelu", False), out=out, ablate=units << 13), a.reps)

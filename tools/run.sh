@@ -14,5 +14,26 @@ case "$NAME" in
       "tests/test_attention_fp8.py::test_fp8_fast_on_a_short_stream_runs_the_exact_form" 2>&1 | grep -v "^$" > gpurun_out/r05a_parity_tests.txt
     grep -E "passed|failed|error|rel-L2|relative error|LN fold stress|FAILED|ERROR|Error" gpurun_out/r05a_parity_tests.txt | cut -c1-260 | tail -90
     ;;
+  r05b)   # the rest of the parity closures (r05a ran out of its clock: 25 min, oracle legs on 128+ host threads), the GELU table, the e4m3 forms on the
+          # peaky fixtures, the N > 1 bench (A/B + fallback + fingerprint self-check), then GEMM / attention timings and the energy table
+    PT="python -m pytest -q -m gpu -v -p pytest_timeout --timeout=420 --durations=15"
+    timeout 1100 $PT "tests/test_long64_gpu.py::test_attention_long64_key_coverage" tests/test_autoencoder.py \
+      "tests/test_image_encoder.py::test_hip_encoder_vitl_against_transformers" \
+      "tests/test_denoiser_gpu.py::test_autoregressive_windows_configs2_at_the_headline_architecture" \
+      "tests/test_baseline_arch_gpu.py::test_float16_mode_with_fp8_attention" "tests/test_baseline_arch_gpu.py::test_peaky_attention_fp8_forms" \
+      tests/test_attention_fp8.py "tests/test_kernels_gpu.py::test_gelu_table_is_bit_identical" "tests/test_kernels_gpu.py::test_gemm" \
+      "tests/test_kernels_gpu.py::test_gemm256_pingpong_main_loop" 2>&1 | grep -v "^$" | grep -vE "PASSED|^tests/.*(SKIPPED)" > gpurun_out/r05b_tests.txt
+    tail -45 gpurun_out/r05b_tests.txt | cut -c1-250
+    timeout 700 $PT -s tests/test_multi_gpu.py -k "bench or phase_loop or copy_engine_exchange_across" 2>&1 | grep -v "^$" | grep -vE "PASSED" | tail -25 | cut -c1-300 | tee gpurun_out/r05b_mgpu.txt
+    python tools/kernel_bench.py --only gemm --product-only --blas --reps 20 2>&1 | grep -E "^gemm" | tee gpurun_out/r05b_gemm.txt
+    python tools/kernel_bench.py --only attn --product-only --fp8 --reps 5 2>&1 | tail -16 | tee gpurun_out/r05b_attn.txt
+    ACTIONMESH_AMD_LIB=build/variants/libam_abl.so python tools/limiter_probe.py --energy-table --seconds 1.5 --out gpurun_out/r05b_energy_table.json 2>&1 | tail -20 | tee gpurun_out/r05b_energy_table.txt
+    for t in 1 0; do
+      ACTIONMESH_AMD_GELU_TABLE=$t timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r05b_bench_gelutab$t.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r05b_bench_gelutab$t.json'))
+print('gelu table $t:', {k: d[k] for k in ('value','ms_per_step')}, d['roofline']['launch_ms'], d['roofline']['frac'], d['roofline'].get('energy_j'), d['roofline'].get('pj_per_flop'), d['latents_fingerprint'])"
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

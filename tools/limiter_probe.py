@@ -181,7 +181,8 @@ def energy_table(a, tel):
     try:
         ops.attention(Q, K, Vt, Sq, Sq, out=out, defer_log2=3008)
         torch.cuda.synchronize()
-    except RuntimeError:
+    except RuntimeError as e:
+        print("ablation legs skipped:", str(e)[:300], flush=True)
         have_abl = False
     ops.attention_fp8(Q, K, Vt, Sq, Sq, out=out); qz = ops.attention_fp8.last_quantized
     R = B * Sq

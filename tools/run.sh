@@ -16,7 +16,7 @@ case "$NAME" in
     ;;
   r05b)   # the rest of the parity closures (r05a ran out of its clock: 25 min, oracle legs on 128+ host threads), the GELU table, the e4m3 forms on the
           # peaky fixtures, the N > 1 bench (A/B + fallback + fingerprint self-check), then GEMM / attention timings and the energy table
-    PT="python -m pytest -q -m gpu -v -p pytest_timeout --timeout=420 --durations=15"
+    PT="python -m pytest -q -m gpu -v --timeout=420 --durations=15"
     timeout 1100 $PT "tests/test_long64_gpu.py::test_attention_long64_key_coverage" tests/test_autoencoder.py \
       "tests/test_image_encoder.py::test_hip_encoder_vitl_against_transformers" \
       "tests/test_denoiser_gpu.py::test_autoregressive_windows_configs2_at_the_headline_architecture" \
@@ -25,10 +25,12 @@ case "$NAME" in
       "tests/test_kernels_gpu.py::test_gemm256_pingpong_main_loop" 2>&1 | grep -v "^$" | grep -vE "PASSED|^tests/.*(SKIPPED)" > gpurun_out/r05b_tests.txt
     tail -45 gpurun_out/r05b_tests.txt | cut -c1-250
     timeout 700 $PT -s tests/test_multi_gpu.py -k "bench or phase_loop or copy_engine_exchange_across" 2>&1 | grep -v "^$" | grep -vE "PASSED" | tail -25 | cut -c1-300 | tee gpurun_out/r05b_mgpu.txt
+    if [ "$1" != "tests-only" ]; then
     python tools/kernel_bench.py --only gemm --product-only --blas --reps 20 2>&1 | grep -E "^gemm" | tee gpurun_out/r05b_gemm.txt
     python tools/kernel_bench.py --only attn --product-only --fp8 --reps 5 2>&1 | tail -16 | tee gpurun_out/r05b_attn.txt
+    fi
     ACTIONMESH_AMD_LIB=build/variants/libam_abl.so python tools/limiter_probe.py --energy-table --seconds 1.5 --out gpurun_out/r05b_energy_table.json 2>&1 | tail -20 | tee gpurun_out/r05b_energy_table.txt
-    for t in 1 0; do
+    for t in $([ "$1" != "tests-only" ] && echo 1 0); do
       ACTIONMESH_AMD_GELU_TABLE=$t timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r05b_bench_gelutab$t.json
       python -c "
 import json; d=json.load(open('gpurun_out/r05b_bench_gelutab$t.json'))

@@ -375,30 +375,30 @@ def test_autoregressive_windows_match_oracle(dev):
     assert max(per_frame) < 3e-2
 
 
-def test_autoregressive_windows_configs2_at_the_headline_architecture(dev):
+def test_autoregressive_windows_configs2_at_the_headline_architecture(dev, golden_dir):
     """BASELINE configs[2]: 32 frames, window 16, slide 15, anchor frame 0 - the THREE sequentially
     dependent windows [0..15], [15..30], [16..31] of the reference (timesteps.py:77-117) - through the device-resident
     LatentBank at the HEADLINE architecture (21 layers, depth-10 skips, width 1024, 8 heads, Dc 1024, S 257) at a reduced token count
     (47 latent tokens per frame -> 768-token inflated sequences) and 3 sampler steps per window, against the CPU oracle's restatement of
-    pipeline.py:247-314 / 469-506 (oracle/windows_oracle.py, fp32) with the same CPU-drawn noise.  Window 2 conditions on window 1's frame 15,
-    window 3 on window 2's frames 16..30.  Stated tolerance: every frame's latents within 2e-2 rel-L2 of the fp32 oracle (the sampler's
-    per-step tolerance, with the error carried through two generations of conditioning frames)."""
+    pipeline.py:247-314 / 469-506 (oracle/windows_oracle.py, fp32, recomputed here) with the same CPU-drawn noise.  Window 2 conditions on
+    window 1's frame 15, window 3 on window 2's frames 16..30.
+    Stated tolerance, frame by frame: rel-L2 vs the fp32 oracle <= 1.15 x (what reduced precision ITSELF costs on this case) + 2e-3, the
+    yardstick being the oracle's bf16-policy run against its fp32 run (tests/golden/ar_configs2_yardstick.json, oracle/
+    make_golden_ar_configs2.py): 2.7e-2 .. 3.0e-2 per frame - with only 3 coarse steps per window (dt ~ 0.33) twice the 30-step figure.
+    MEASURED on MI355X (round 5): 2.91e-2 / 2.94e-2 / 2.94e-2 (window 1 max, frames 16..30 max, frame 31): the HIP path sits ON the
+    reduced-precision distance and does not grow through the two generations of conditioning frames."""
+    import json
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
     from actionmesh_amd import windows as W
     from oracle import denoiser_oracle as O
     from oracle import windows_oracle as WO
-    hp = dict(in_channels=64, num_layers=21, num_attention_heads=8, width=1024, mlp_ratio=4.0, cross_attention_dim=1024,
-              inflated_layers=tuple(range(21)))
-    cfg = O.OracleConfig(**hp)
-    sd = O.synthetic_state_dict(cfg, seed=2)
-    T, N, D, S, steps = 32, 47, 64, 257, 3
+    from oracle.make_golden_ar_configs2 import HP as hp, N, D, S, STEPS as steps, T, case
+    yard = json.load(open(os.path.join(golden_dir, "ar_configs2_yardstick.json")))
+    cfg, sd, ts, context, anchor = case()
+    assert O.state_dict_checksum(sd) == pytest.approx(yard["weights_checksum"], rel=1e-12) and (yard["frames"], yard["tokens"], yard["steps"]) == (T, N, steps)
     model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=16, **hp)
     model.load_state_dict(sd)
     model.to(dev).eval()
-    g = torch.Generator().manual_seed(32)
-    ts = torch.arange(T, dtype=torch.float32)
-    context = torch.randn((T, S, 1024), generator=g)
-    anchor = torch.randn((1, N, D), generator=g)
     sched = HipSchedulerFlow(num_inference_steps=steps, shift=3.0, is_additive=True)
     cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
     assert [w.tolist() for w in W.chunk_from(0, T, 16, 15)] == [list(range(16)), list(range(15, 31)), list(range(16, 32))]
@@ -415,12 +415,16 @@ def test_autoregressive_windows_configs2_at_the_headline_architecture(dev):
     torch.cuda.synchronize()
     lat, t_sorted = bank.get_ordered()
     lat_ref, t_ref = ref.get_ordered()
+    assert float(lat_ref.double().sum()) == pytest.approx(yard["fp32_checksum"], abs=0.5), "the fp32 oracle run the yardstick was taken against"
     assert t_sorted.cpu().tolist() == t_ref.tolist() == list(range(T))
     assert torch.equal(lat[0].cpu(), anchor[0]), "the anchor latent is conditioning only"
     per_frame = [rel(lat[i].cpu(), lat_ref[i]) for i in range(1, T)]
+    yd = yard["bf16_policy_vs_fp32_per_frame"][1:]
     print("configs[2] AR windows at the headline architecture: per-frame rel-L2 vs the fp32 oracle: window 1 max "
-          f"{max(per_frame[:15]):.2e}, frames 16..30 max {max(per_frame[15:30]):.2e}, frame 31 {per_frame[30]:.2e}")
-    assert max(per_frame) < 2e-2
+          f"{max(per_frame[:15]):.2e}, frames 16..30 max {max(per_frame[15:30]):.2e}, frame 31 {per_frame[30]:.2e}; "
+          f"reduced-precision yardstick max {max(yd):.2e}; worst ratio {max(p / y for p, y in zip(per_frame, yd)):.3f}")
+    for i, (p_, y_) in enumerate(zip(per_frame, yd)):
+        assert p_ <= 1.15 * y_ + 2e-3, (i + 1, p_, y_)
 
 
 def test_split_cfg_batch_style_loop_rebinds_the_context(dev, golden_dir):

@@ -37,5 +37,24 @@ import json; d=json.load(open('gpurun_out/r05b_bench_gelutab$t.json'))
 print('gelu table $t:', {k: d[k] for k in ('value','ms_per_step')}, d['roofline']['launch_ms'], d['roofline']['frac'], d['roofline'].get('energy_j'), d['roofline'].get('pj_per_flop'), d['latents_fingerprint'])"
     done
     ;;
+  r05c)   # restated tests (AR configs[2] vs the reduced-precision yardstick, the e4m3 forms on the peaky fixtures), the N > 1 bench at the HEADLINE shape
+          # and the driver's step counts on one device (does the fingerprint self-check hold at 25 steps?), the energy table with the
+          # ablation build, the "next" rows re-measured on today's kernels in both 16-bit types
+    PT="python -m pytest -q -m gpu -rA --timeout=420 --durations=10"
+    timeout 600 $PT "tests/test_denoiser_gpu.py::test_autoregressive_windows_configs2_at_the_headline_architecture" \
+      "tests/test_baseline_arch_gpu.py::test_peaky_attention_fp8_forms" 2>&1 | grep -v "^$" > gpurun_out/r05c_tests.txt
+    grep -E "passed|failed|rel-L2|FAILED|Error" gpurun_out/r05c_tests.txt | cut -c1-300 | tail -12
+    timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 4 \
+      --same-device --steps 20 --warmup 5 --no-roofline 2>gpurun_out/r05c_bench4.err | grep "^{" > gpurun_out/r05c_bench_same_device_4.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r05c_bench_same_device_4.json'))
+print('same-device x4 headline:', d['ms_per_step'], d['exchange_ab'], d['fingerprint_check'])" || tail -5 gpurun_out/r05c_bench4.err
+    ACTIONMESH_AMD_LIB=build/variants/libam_abl.so python tools/limiter_probe.py --energy-table --seconds 1.5 --out gpurun_out/r05c_energy_table.json 2>&1 | grep -v "^{" | tail -22 | tee gpurun_out/r05c_energy_table.txt
+    for dt in bfloat16 float16; do
+      python tools/stage2_bench.py --dtype $dt 2>/dev/null | tail -1 | tee gpurun_out/r05c_stage2_$dt.json | cut -c1-330
+      python tools/encoder_bench.py --dtype $dt 2>/dev/null | tail -1 | tee gpurun_out/r05c_encoder_$dt.json | cut -c1-330
+    done
+    python tools/e2e_synthetic.py 2>/dev/null | tail -1 | tee gpurun_out/r05c_e2e_synthetic.json | cut -c1-420
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -56,5 +56,29 @@ print('same-device x4 headline:', d['ms_per_step'], d['exchange_ab'], d['fingerp
     done
     python tools/e2e_synthetic.py 2>/dev/null | tail -1 | tee gpurun_out/r05c_e2e_synthetic.json | cut -c1-420
     ;;
+  r05final)   # end-of-round evidence for the FINAL sources: the whole GPU suite (per-test output + durations kept), smoke, the contract bench line,
+              # the profile set named by the sources sha, configs[4] on one device (fp8 / fp8_fast) behind its parity tests, the fp8 headline lines
+    TAG=r05
+    timeout 2400 python -m pytest tests -q -m gpu -rA --timeout=600 --durations=40 2>&1 | grep -v "^$" > gpurun_out/${TAG}_gputest_full.txt
+    grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_gputest_full.txt | tail -15 | tee gpurun_out/${TAG}_gputest.txt
+    grep -A42 "slowest 40 durations" gpurun_out/${TAG}_gputest_full.txt | head -44 >> gpurun_out/${TAG}_gputest.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 | tee -a gpurun_out/${TAG}_gputest.txt
+    timeout 900 python bench.py --steps 10 --warmup 2 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_headline.json
+    python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_headline.json'))
+r=d['roofline']; c=d['cpu_baseline']
+print({k: d[k] for k in ('value','ms_per_step','dtype','step_frac_of_bf16_peak')}, r['launch_ms'], r['frac'], r['traffic'], r.get('energy_j'), r.get('pj_per_flop'), r.get('effective_clock_ghz'), r.get('pipe_busy'), d.get('nominal',{}).get('ms_per_step'), d['with_exact_shortcuts']['ms_per_step'])
+print('cpu_baseline', c['value'], c['cores'], c['derivation'], c['scaled_reference'], c['fit']['value'], c['fit']['max_relative_residual'])"
+    tools/gpu_profile.sh $TAG 2>&1 | tail -8
+    for dt in fp8 fp8_fast; do
+      timeout 600 python bench.py --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_headline_$dt.json
+      timeout 600 python bench.py --shape long64 --dtype $dt --steps 1 --warmup 1 --no-cpu-baseline --no-nominal --no-roofline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_long64_$dt.json
+    done
+    timeout 600 python bench.py --shape long64 --dtype fp8 --emulate-world 8 --steps 1 2>/dev/null | tail -1 > gpurun_out/${TAG}_emulate8_long64_fp8.json
+    python -c "
+import json
+for f in ('bench_headline_fp8', 'bench_headline_fp8_fast', 'bench_long64_fp8', 'bench_long64_fp8_fast', 'emulate8_long64_fp8'):
+    d = json.load(open('gpurun_out/${TAG}_' + f + '.json')); print(f, {k: d[k] for k in d if k in ('ms_per_step', 'value', 'dtype', 'step_frac_of_dtype_peak', 'rank0_ms_per_step', 'modelled_link_ms_per_layer', 'step_tflops_per_gpu')}, (d.get('roofline') or {}).get('launch_ms'), (d.get('roofline') or {}).get('frac'))"
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -227,8 +227,9 @@ def _long64_case():
 @pytest.mark.parametrize("dtype", ["bf16", "fp8", "fp8_fast"])
 def test_one_layer_model_at_long64(dev, dtype):
     """Stated tolerance on the velocity of the 48 sampled tokens vs the fp32 oracle: bf16 rel-L2 <= 1e-2 (one layer of bf16 rounding:
-    the 21-layer forward is 9.8e-3); fp8 / fp8_fast <= 4e-2 - the e4m3 noise of the self-attention (<= 6e-2 of its output at unit
-    scores, more at these 3.2-sigma scores) on a branch that carries ~20 % of the residual stream.  Measured values are printed."""
+    the 21-layer forward is 9.8e-3); fp8 / fp8_fast <= 2e-2 - the e4m3 noise of the self-attention (<= 6e-2 of its output at unit
+    scores, more at these 3.2-sigma scores) on a branch that carries ~20 % of the residual stream; worst single token <= 3 x.
+    MEASURED on MI355X (round 5): bf16 5.2e-3 (worst token 6.4e-3), fp8 8.1e-3 (1.6e-2), fp8_fast 1.2e-2 (3.4e-2)."""
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser
     from oracle import denoiser_oracle as O
     hp, cfg, sd, x, ctx, mask, fs, rows = _long64_case()
@@ -252,6 +253,6 @@ def test_one_layer_model_at_long64(dev, dtype):
     r = _rel(got, ref)
     worst = max(_rel(g_, w_) for g_, w_ in zip(got, ref))
     print(f"one-layer model at 64 x 8192 tokens, {dtype}: sampled-row velocity rel-L2 vs the fp32 oracle {r:.3e} (worst row {worst:.3e})")
-    tol = 1e-2 if dtype == "bf16" else 4e-2
+    tol = 1e-2 if dtype == "bf16" else 2e-2
     assert r <= tol and worst <= 3 * tol, f"{dtype}: {r:.3e} / worst row {worst:.3e} (tol {tol})"
     model._engine.close()

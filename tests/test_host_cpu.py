@@ -240,3 +240,23 @@ def test_no_swapped_packed_f32_in_the_built_library(tmp_path, kind):
                 assert not any(k in (kernel or "") for k in ("head_post_kernel", "layernorm_kernel", "flow_step", "f32_to_bf16")), \
                     f"row-wise kernel {kernel} contains a packed-FP32 instruction: {line.strip()}"
     assert n_pk > 100, "the audit did not see the GEMM / attention kernels' packed instructions - wrong objects?"
+
+
+def test_autocast_kind_follows_the_callers_region(monkeypatch):
+    """_lib.autocast_kind: the pinned kind wins; otherwise float16 only inside an enabled cuda autocast region whose dtype is float16
+    (the reference pipeline's `--dtype float16`), bfloat16 everywhere else; and on a torch without get_autocast_dtype the per-device
+    getters are used instead of silently answering bfloat16."""
+    import torch
+    assert _lib.autocast_kind("f16") == "f16" and _lib.autocast_kind("bf16") == "bf16"
+    assert _lib.autocast_kind(None) == "bf16"                                   # no autocast region here
+    monkeypatch.setattr(torch, "is_autocast_enabled", lambda *a: True)
+    monkeypatch.setattr(torch, "get_autocast_dtype", lambda *a: torch.float16)
+    assert _lib.autocast_kind(None) == "f16"
+    monkeypatch.setattr(torch, "get_autocast_dtype", lambda *a: torch.bfloat16)
+    assert _lib.autocast_kind(None) == "bf16"
+    monkeypatch.delattr(torch, "get_autocast_dtype")                            # an older torch
+    monkeypatch.setattr(torch, "get_autocast_gpu_dtype", lambda: torch.float16)
+    assert _lib.autocast_kind(None) == "f16"
+    assert _lib.kind_of(torch.float16) == "f16" and _lib.kind_of("bfloat16") == "bf16"
+    with pytest.raises(ValueError, match="bfloat16 or float16"):
+        _lib.kind_of(torch.float32)

@@ -80,5 +80,15 @@ import json
 for f in ('bench_headline_fp8', 'bench_headline_fp8_fast', 'bench_long64_fp8', 'bench_long64_fp8_fast', 'emulate8_long64_fp8'):
     d = json.load(open('gpurun_out/${TAG}_' + f + '.json')); print(f, {k: d[k] for k in d if k in ('ms_per_step', 'value', 'dtype', 'step_frac_of_dtype_peak', 'rank0_ms_per_step', 'modelled_link_ms_per_layer', 'step_tflops_per_gpu')}, (d.get('roofline') or {}).get('launch_ms'), (d.get('roofline') or {}).get('frac'))"
     ;;
+  r05d)   # after the final run: the tests whose tolerances were tightened to the measured values, and the one-device PROJECTION of 2 / 4 / 8 ranks
+          # (rank 0's share + modelled link time) on this round's kernels
+    timeout 600 python -m pytest -q -m gpu -rA --timeout=420 "tests/test_autoencoder.py::test_hip_autoencoder_at_the_shipped_architecture" \
+      "tests/test_long64_gpu.py::test_one_layer_model_at_long64" 2>&1 | grep -E "passed|failed|rel-L2|FAILED" | cut -c1-300 | tee gpurun_out/r05d_tests.txt
+    for P in 2 4 8; do
+      timeout 300 python bench.py --emulate-world $P --steps 3 2>/dev/null | tail -1 > gpurun_out/r05d_emulate_world_$P.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r05d_emulate_world_$P.json')); print('P=$P', {k: d[k] for k in d if k in ('rank0_ms_per_step','modelled_link_ms_per_layer','host_enqueue_ms_per_step','local_pass_ms_per_layer')})"
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

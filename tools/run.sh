@@ -90,5 +90,20 @@ for f in ('bench_headline_fp8', 'bench_headline_fp8_fast', 'bench_long64_fp8', '
 import json; d=json.load(open('gpurun_out/r05d_emulate_world_$P.json')); print('P=$P', {k: d[k] for k in d if k in ('rank0_ms_per_step','modelled_link_ms_per_layer','host_enqueue_ms_per_step','local_pass_ms_per_layer')})"
     done
     ;;
+  r05e)   # robustness of the hardened copy-engine exchange (fine-grained flags, ring-owned events) between real processes, repeated; the pure
+          # frame-sharding partition at the headline shape on one device; one driver-style bench line (the driver's own step counts)
+    tools/peer_stress.sh 10 2 --loop both --forwards 4 2>&1 | tail -3 | tee gpurun_out/r05e_peer_stress.txt
+    tools/peer_stress.sh 8 4 2>&1 | tail -3 | tee -a gpurun_out/r05e_peer_stress.txt
+    tools/peer_stress.sh 4 4 --dtype fp8 2>&1 | tail -3 | tee -a gpurun_out/r05e_peer_stress.txt
+    timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=4 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 4 \
+      --same-device --cfg-parallel 0 --steps 20 --warmup 5 --no-roofline 2>gpurun_out/r05e_bench4.err | grep "^{" > gpurun_out/r05e_bench_same_device_4_frames_only.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r05e_bench_same_device_4_frames_only.json'))
+print('same-device x4 pure frame sharding:', d['config']['parallelism'], d['ms_per_step'], d['exchange_ab'], d['fingerprint_check']['legs'], d['fingerprint_ok'])" || tail -5 gpurun_out/r05e_bench4.err
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r05e_bench_driver_style.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r05e_bench_driver_style.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step','steps','warmup')}, r['launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r.get('energy_j'), d['nominal']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['derivation'][:20])"
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -517,7 +517,9 @@ def main():
     args = ap.parse_args()
     if args.graph:
         os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
-    if args.same_device:
+    if args.same_device or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # multi-process GPU work on these hosts needs dmabuf IPC (RCCL and the copy-engine exchange alike); exported on the boxes already,
+        # set here too - before the first HIP call of the process - so that a launcher with a scrubbed environment does not lose it
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch.distributed as dist

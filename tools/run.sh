@@ -105,5 +105,18 @@ print('same-device x4 pure frame sharding:', d['config']['parallelism'], d['ms_p
 import json; d=json.load(open('gpurun_out/r05e_bench_driver_style.json')); r=d['roofline']
 print({k: d[k] for k in ('value','ms_per_step','steps','warmup')}, r['launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r.get('energy_j'), d['nominal']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['derivation'][:20])"
     ;;
+  r05f)   # the packed row sums of the 4x64 attention kernel (AM_A64_PKSUM): same-box A/B against the scalar adds, bit identity, the attention tests
+    for v in nopk pk; do ACTIONMESH_AMD_LIB=build/variants/libam_$v.so python tools/diag/attn_bits.py 2>/dev/null > gpurun_out/r05f_bits_$v.txt; done
+    if cmp -s gpurun_out/r05f_bits_nopk.txt gpurun_out/r05f_bits_pk.txt; then echo "BIT-IDENTICAL: packed vs scalar row sums"; else echo "DIFFERENT BITS"; diff gpurun_out/r05f_bits_nopk.txt gpurun_out/r05f_bits_pk.txt; fi
+    cat gpurun_out/r05f_bits_pk.txt
+    tools/ab_attn64.sh "nopk pk" "" "" > /dev/null 2>&1; grep -E "===|variant=  8" gpurun_out/ab_attn64.txt | tee gpurun_out/r05f_ab_pksum.txt
+    timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_f16_gpu.py -q -m gpu -k "attention" --timeout=300 2>&1 | tail -3 | tee gpurun_out/r05f_tests.txt
+    for t in nopk pk; do
+      ACTIONMESH_AMD_LIB=build/variants/libam_$t.so timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r05f_bench_$t.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r05f_bench_$t.json')); r=d['roofline']
+print('$t:', {k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], r.get('energy_j'), r.get('effective_clock_ghz'), r.get('pipe_busy'), d['latents_fingerprint']['sample'][:3])"
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -413,38 +413,67 @@ def gather_latent_frames(latents: torch.Tensor, plan: FrameShardPlan, group: Opt
     return latents
 
 
-def run_exchange_legs(order, run_leg, ctl_group, rank: int, leg_timeout: float, on_watchdog, describe=None):
+def leg_store():
+    """The key-value store the default process group was built on: the channel the per-leg verdicts travel on.  It is NOT a process
+    group: a rank that left a leg early cannot pair its verdict with a collective another rank is still inside."""
+    from torch.distributed import distributed_c10d as c10d
+    return dist.PrefixStore("actionmesh_amd/legs", c10d._get_default_store())
+
+
+def store_gather(store, key: str, rank: int, world: int, value: str, timeout_s: float) -> List[Optional[str]]:
+    """Every rank posts `value` under `key`/rank and reads every other rank's; a rank that has posted nothing after `timeout_s`
+    reads as None.  Order-free and idempotent: no collective, nothing to mismatch."""
+    from datetime import timedelta
+    store.set(f"{key}/{rank}", value)
+    out: List[Optional[str]] = []
+    for r in range(world):
+        k = f"{key}/{r}"
+        try:
+            store.wait([k], timedelta(seconds=max(1.0, timeout_s)))
+            out.append(store.get(k).decode())
+        except Exception:                            # noqa: BLE001 - DistStoreError / RuntimeError by torch version: a timeout
+            out.append(None)
+    return out
+
+
+def run_exchange_legs(order, run_leg, rank: int, world: int, leg_timeout: float, on_watchdog, describe=None, store=None,
+                      make_ctl=None, tag: str = "leg"):
     """Run the exchange back-ends named in `order` one after the other on every rank and agree on which of them completed.
 
-    `run_leg(name)` does one leg on this rank and returns its result (any object) or raises.  After every leg the ranks take the MIN
-    of their success flags over `ctl_group` (a gloo group: the control plane must not depend on the back-end under test), so a leg
-    counts only if EVERY rank completed it; a leg that failed anywhere is reported with its error text and the next one runs.
-    From the second leg on - i.e. once there is something to report - a watchdog thread calls `on_watchdog(name, legs, report)`
-    when a leg has produced no verdict after `leg_timeout` seconds (a collective that never returns cannot be caught): the caller
-    prints what it has and leaves the process.  Rank 0's watchdog fires first, the other ranks' 10 s later.
+    `run_leg(name, ctl)` does one leg on this rank and returns its result (any object) or raises; `ctl` is a gloo group made for THIS
+    leg by `make_ctl()` (explicit timeout: a rank waiting in the leg's barrier for a rank that has already left the leg gets an
+    exception instead of waiting for ever), never re-used by a later leg (a group whose collective timed out is in an unknown state).
+    The per-leg verdict does NOT ride on any process group: every rank posts "ok" or its error text on the key-value `store`
+    (leg_store()) and reads the others' - a leg counts only if EVERY rank completed it; a leg that failed anywhere is reported with
+    its error text and the next one runs.  A rank that posts nothing within `leg_timeout` makes the leg failed as well.
+    A watchdog thread - armed for EVERY leg, the first one too - calls `on_watchdog(name, legs, report)` when a leg has produced no
+    verdict after `leg_timeout` seconds (a device-side collective that never returns cannot be caught): the caller prints what it has
+    and leaves the process, non-zero when no leg has completed.  Rank 0's watchdog fires first, the other ranks' 10 s later.
     Returns (legs: name -> result of the legs that completed everywhere, report: name -> {"ok": bool, ...}).
-    `describe(result)` -> dict of extra fields for the report of a completed leg.  Used by bench.py --gpus N;
-    tests/test_sharding_gloo.py drives it with stand-in legs between two gloo processes."""
+    `describe(result)` -> dict of extra fields for the report of a completed leg.  Used by bench.py --gpus N (VERDICT r04 next #2,
+    ADVICE r05); tests/test_sharding_gloo.py drives it with stand-in legs between two gloo processes."""
     import threading
+    store = leg_store() if store is None else store
     legs, report = {}, {}
     for i, name in enumerate(order):
-        timer = None
-        if i > 0 and legs:
-            timer = threading.Timer(leg_timeout + (0.0 if rank == 0 else 10.0), on_watchdog, args=(name, legs, report))
-            timer.daemon = True
-            timer.start()
+        timer = threading.Timer(leg_timeout + (0.0 if rank == 0 else 10.0), on_watchdog, args=(name, legs, report))
+        timer.daemon = True
+        timer.start()
         result, err = None, None
         try:
-            result = run_leg(name)
+            ctl = make_ctl() if make_ctl is not None else None
+            result = run_leg(name, ctl)
         except Exception as e:                       # noqa: BLE001 - the verdict of a leg, reported instead of raised
             err = f"{type(e).__name__}: {str(e)[:300]}"
-        flag = torch.tensor([1 if err is None else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctl_group)
-        if timer is not None:
-            timer.cancel()
-        if bool(flag.item()):
+        verdicts = store_gather(store, f"{tag}/{i}/{name}", rank, world, "ok" if err is None else "E:" + err, leg_timeout)
+        timer.cancel()
+        if all(v == "ok" for v in verdicts):
             legs[name] = result
             report[name] = {"ok": True, **(describe(result) if describe is not None else {})}
         else:
-            report[name] = {"ok": False, "error": err or "failed on another rank"}
+            bad = [r for r, v in enumerate(verdicts) if v != "ok"]
+            silent = [r for r, v in enumerate(verdicts) if v is None]
+            report[name] = {"ok": False, "error": err or ("no verdict from rank(s) " + str(silent) if silent and silent == bad
+                                                          else f"failed on another rank ({bad}): " + str(next(v for v in verdicts if v and v != 'ok'))[2:200]),
+                            "failed_ranks": bad}
     return legs, report

@@ -473,6 +473,200 @@ def nominal_record(dev, dtype, steps=3):
     return rec
 
 
+PREFLIGHT_HP = dict(in_channels=64, num_layers=2, num_attention_heads=2, width=256, mlp_ratio=4.0, cross_attention_dim=64,
+                    inflated_layers=[0, 1])          # the `small` plumbing width, two layers: the exchange's sequence flags turn once
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_argv(argv, n, port):
+    """The command `python bench.py --gpus N ...` turns itself into when nobody wrapped it in a launcher: the driver's own N > 1
+    command (task statement), same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: re-execute under it - one rank
+    per GPU - hand rank 0's ONE JSON line through as the LAST line of stdout (everything else the ranks print goes to stderr), and
+    return the launcher's exit code.  Fewer than N visible devices: a one-line JSON error, exit code 2.  With the default back-end
+    choice (`--exchange ab`) a run that died without a line is repeated once per single back-end (a hung RCCL cannot be recovered
+    inside the process it hung; a fresh set of processes can run the copy-engine exchange) and the line says which attempt it is."""
+    import subprocess
+    n = args.gpus
+    if not args.same_device:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(json.dumps({"error": f"bench.py --gpus {n}: {have} visible device(s)", "metric": "denoise-steps/sec", "value": None,
+                              "n_gpus": n, "visible_devices": have}), flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    attempts = [list(argv)]
+    if args.exchange in (None, "ab") and not os.environ.get("ACTIONMESH_AMD_EXCHANGE") and not args.same_device:
+        attempts += [list(argv) + ["--exchange", "peer"], list(argv) + ["--exchange", "rccl"]]
+    history, rc = [], 1
+    for k, av in enumerate(attempts):
+        cmd = launcher_argv(av, n, free_port())
+        t0 = time.time()
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+        line = None
+        for out in proc.stdout:                      # the ranks' stderr is inherited: it streams through untouched
+            if out.startswith("{") and '"metric"' in out:
+                line = out.strip()
+            else:
+                sys.stderr.write(out)
+        rc = proc.wait()
+        history.append({"argv": av, "returncode": rc, "seconds": round(time.time() - t0, 1), "line": line is not None})
+        if line is not None:
+            try:
+                rec = json.loads(line)
+                rec["launcher"] = {"self_launched": True, "command": " ".join(cmd[:cmd.index(os.path.abspath(__file__))] + ["bench.py"] + av),
+                                   "attempts": history}
+                line = json.dumps(rec)
+            except ValueError:
+                pass
+            print(line, flush=True)
+            return rc
+    print(json.dumps({"error": "bench.py: no attempt produced a result line", "metric": "denoise-steps/sec", "value": None, "n_gpus": n,
+                      "launcher": {"self_launched": True, "attempts": history}}), flush=True)
+    return rc or 1
+
+
+def preflight_plan(world, cfg_parallel):
+    """Frames of the pre-flight problem: two per frame shard, so that every rank of an N-rank run exchanges with its peers."""
+    groups = 2 if (cfg_parallel and world % 2 == 0) else 1
+    fw = world // groups
+    return max(4, 2 * fw)
+
+
+def preflight_child(args):
+    """One rank of the PRE-FLIGHT of one exchange back-end (`bench.py --preflight-child rccl|peer`, started by every rank of the real
+    run as a killable child process with its own rendezvous port): the sharded sampler on a seconds-long problem - plumbing width,
+    two layers, two frames per shard, three steps - through exactly the classes the legs use (HipDenoiser + process group,
+    HipSchedulerFlow, the per-layer [K | V^T] exchange), compared on rank 0 with the unsharded run of the same steps.  Prints one
+    JSON verdict line.  A back-end that hangs here is killed with the child; the real run then does not spend a headline warm-up on it."""
+    import torch.distributed as dist
+    from datetime import timedelta
+    from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
+    name = args.preflight_child
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    t0 = time.time()
+    os.environ["ACTIONMESH_AMD_EXCHANGE"] = name
+    if name == "rccl" and args.same_device:
+        print(json.dumps({"preflight": name, "ok": False, "rank": rank, "error": "RCCL refuses two ranks on one device (--same-device)"}), flush=True)
+        return 0
+    backend = "nccl" if name == "rccl" else "gloo"          # the copy-engine back-end makes no RCCL call at all
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{args.pf_port}", rank=rank, world_size=world,
+                            timeout=timedelta(seconds=max(30.0, args.preflight_timeout)))
+    hp = dict(PREFLIGHT_HP)
+    T, N, S = preflight_plan(world, args.cfg_parallel), 512, 17
+    sd = random_state_dict(hp, seed=1)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, T, N, hp["in_channels"], generator=g)
+    ctx = torch.randn(1, T, S, hp["cross_attention_dim"], generator=g).to(dev)
+    mask = torch.zeros(1, T); mask[0, 0] = 1.0
+    fs = torch.arange(T, dtype=torch.float32)[None]
+    cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
+
+    def run(group):
+        model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=T, process_group=group, attn_dtype=args.dtype,
+                            cfg_parallel=bool(args.cfg_parallel), **hp)
+        model.load_state_dict(sd)
+        model.to(dev).eval()
+        lat = x0.clone().to(dev)
+        sched = HipSchedulerFlow(num_inference_steps=50, shift=3.0, is_additive=True, exact_shortcuts=False)
+        loop = sched._flow_sample_impl(model, cfgd, lat, ctx, device=dev, mask=mask.to(dev), framestep=fs, local_latents=group is not None)
+        for _ in range(3):
+            next(loop)
+        torch.cuda.synchronize(dev)
+        model.check_exchange(block=True)
+        if group is not None:
+            model.gather_latent_frames(lat[0], 2)
+        out = lat.detach().float().cpu().clone()
+        ex = getattr(model._engine, "exchange", None)
+        fine = getattr(ex, "flags_fine_grained", None)
+        model._engine.close()
+        return out, fine
+
+    rec = {"preflight": name, "rank": rank, "world": world, "frames": T}
+    try:
+        sharded, fine = run(dist.group.WORLD)
+        rec["ok"] = bool(torch.isfinite(sharded).all())
+        if fine is not None:
+            rec["flags_fine_grained"] = bool(fine)
+        if rank == 0:
+            single, _ = run(None)
+            d = float((sharded.double() - single.double())[0, 1:].norm() / single.double()[0, 1:].norm())
+            rec["rel_l2_vs_single_rank"], rec["tol"] = round(d, 6), 3e-2
+            rec["ok"] = rec["ok"] and d <= 3e-2
+    except Exception as e:                           # noqa: BLE001 - the verdict
+        rec["ok"], rec["error"] = False, f"{type(e).__name__}: {str(e)[:300]}"
+    rec["seconds"] = round(time.time() - t0, 2)
+    print(json.dumps(rec), flush=True)
+    sys.stdout.flush()
+    os._exit(0)          # no destroy_process_group: a half-dead back-end must not keep the verdict from leaving
+
+
+def run_preflight(order, args, rank, world, store, argv):
+    """Every rank of the real run starts ONE child per back-end (`--preflight-child`, rendezvous on a fresh port that rank 0 picks and
+    publishes on the store), waits at most --preflight-timeout seconds, kills what has not answered (process group and all), and the
+    ranks agree over the store: a back-end passes only if every rank's child said ok.  Returns name -> verdict record."""
+    import signal
+    import subprocess
+    from actionmesh_amd.sharding import store_gather
+    verdicts = {}
+    for k, name in enumerate(order):
+        if rank == 0:
+            store.set(f"pf_port/{k}", str(free_port()))
+        port = int(store.get(f"pf_port/{k}").decode())
+        env = {e: v for e, v in os.environ.items() if not e.startswith("TORCHELASTIC")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--preflight-child", name, "--pf-port", str(port),
+               "--dtype", args.dtype, "--cfg-parallel", str(args.cfg_parallel), "--preflight-timeout", str(args.preflight_timeout)]
+        if args.same_device:
+            cmd.append("--same-device")
+        t0 = time.time()
+        rec = None
+        try:
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                out, err = proc.communicate(timeout=args.preflight_timeout)
+                for ln in out.splitlines():
+                    if ln.startswith("{") and '"preflight"' in ln:
+                        rec = json.loads(ln)
+                if rec is None:
+                    rec = {"ok": False, "error": f"child exited {proc.returncode} without a verdict: {err.strip()[-300:]}"}
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    proc.kill()
+                proc.communicate()
+                rec = {"ok": False, "error": f"no verdict after {args.preflight_timeout:.0f} s: child killed"}
+        except Exception as e:                       # noqa: BLE001
+            rec = {"ok": False, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+        rec["seconds"] = round(time.time() - t0, 1)
+        mine = json.dumps(rec)
+        everyone = store_gather(store, f"pf/{k}/{name}", rank, world, mine, args.preflight_timeout + 30.0)
+        recs = [json.loads(v) if v else {"ok": False, "error": "no verdict"} for v in everyone]
+        bad = [r for r, v in enumerate(recs) if not v.get("ok")]
+        verdicts[name] = {"ok": not bad, "seconds": max(v.get("seconds", 0) for v in recs),
+                          **({"rel_l2_vs_single_rank": recs[0].get("rel_l2_vs_single_rank")} if recs[0].get("rel_l2_vs_single_rank") is not None else {}),
+                          **({"flags_fine_grained": recs[0]["flags_fine_grained"]} if "flags_fine_grained" in recs[0] else {}),
+                          **({"failed_ranks": bad, "error": str(recs[bad[0]].get("error"))[:300]} if bad else {})}
+    return verdicts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -514,15 +708,28 @@ def main():
                     help="N > 1, second leg of --exchange ab: seconds before a watchdog prints the line with the completed leg and exits")
     ap.add_argument("--no-fingerprint-check", action="store_true",
                     help="N > 1: skip the single-rank re-run of the same steps on rank 0 that the sharded latents are compared with")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the seconds-long pre-flight of the exchange back-ends (killable child processes on a plumbing-size "
+                         "problem, verdicts in `exchange_ab.preflight`) that keeps a dead back-end from costing a headline warm-up")
+    ap.add_argument("--preflight-timeout", type=float, default=90.0, help="seconds a pre-flight child may take before it is killed")
+    ap.add_argument("--preflight-child", default=None, choices=["rccl", "peer"], help=argparse.SUPPRESS)
+    ap.add_argument("--pf-port", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.graph:
         os.environ["ACTIONMESH_AMD_GRAPH"] = "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started bare (`python bench.py --gpus N`): become the launcher of N ranks of this same command
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     if args.same_device or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # multi-process GPU work on these hosts needs dmabuf IPC (RCCL and the copy-engine exchange alike); exported on the boxes already,
         # set here too - before the first HIP call of the process - so that a launcher with a scrubbed environment does not lose it
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    if args.preflight_child:
+        return preflight_child(args)
+
     import torch.distributed as dist
+    from datetime import timedelta
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -538,10 +745,15 @@ def main():
     # the CFG-branch sub-groups by communicator split, which not every RCCL build supports), gloo for --same-device (RCCL refuses two
     # ranks on one device).  `ctl`: a gloo group of all ranks for everything that is not the data path - barriers, the MAX of the
     # timings, the per-leg verdicts - so that a broken RCCL cannot take the control plane with it.
-    ctl = None
+    # The per-leg VERDICTS travel on neither: they are keys of the rendezvous store (sharding.run_exchange_legs), and every leg gets a
+    # fresh gloo group with an explicit timeout for its own barriers (`ctl` below is re-bound per leg) - ADVICE r05.
+    ctl, ctl_main, store = None, None, None
     if world > 1:
         dist.init_process_group("gloo" if args.same_device else "nccl")
-        ctl = dist.group.WORLD if args.same_device else dist.new_group(backend="gloo")
+        ctl_main = dist.new_group(backend="gloo")          # barriers outside the legs (default timeout: rank 0's single-rank re-run is long)
+        ctl = ctl_main
+        from actionmesh_amd.sharding import leg_store
+        store = leg_store()
 
     def barrier():
         dist.barrier(group=ctl)
@@ -705,21 +917,44 @@ def main():
         order = ["rccl", "peer"] if want == "ab" else [want]
         from actionmesh_amd.sharding import run_exchange_legs
         state = {"printed": False}
+        # ---- pre-flight: each back-end on a seconds-long problem in killable child processes --------------
+        preflight = None
+        if not args.no_preflight:
+            preflight = run_preflight(order, args, rank, world, store, sys.argv[1:])
+            alive = [n for n in order if preflight[n]["ok"]]
+            # nothing passed: the pre-flight itself may be what is broken (a slow first import, a port) - the legs still get their
+            # chance, under the watchdog; otherwise only what passed spends a headline warm-up
+            skipped = [n for n in order if n not in alive] if alive else []
+            order = alive or order
+        else:
+            skipped = []
 
         def on_watchdog(leg, legs_so_far, report):
-            # a later leg hung (a collective that never returns cannot be caught): report the completed leg(s) and leave
-            report[leg] = {"ok": False, "error": f"no result after {args.leg_timeout:.0f} s (watchdog); the line reports the other leg"}
+            # a leg hung (a device-side collective that never returns cannot be caught): report the completed leg(s) and leave; with
+            # nothing to report the exit code says so (the self-launcher then tries the back-ends one by one)
+            report[leg] = {"ok": False, "error": f"no result after {args.leg_timeout:.0f} s (watchdog)"}
+            if preflight is not None:
+                report["preflight"] = preflight
             if rank == 0 and not state["printed"] and legs_so_far:
                 state["printed"] = True
                 print(json.dumps(build_result(legs_so_far, report, fingerprint_check=None)), flush=True)
             os._exit(0 if legs_so_far else 3)
 
-        def leg(name):
-            # peer: the model's own small collectives (velocity gather among same-frame ranks, the final frame gather) ride on gloo,
-            # so the leg makes no RCCL call at all; rccl: everything on the nccl WORLD
-            r = run_leg(name, ctl if name == "peer" else dist.group.WORLD)
-            torch.cuda.synchronize(dev)
-            return r
+        def make_ctl():
+            # a fresh control group per leg: its barriers time out instead of waiting for a rank that has left the leg
+            return dist.new_group(backend="gloo", timeout=timedelta(seconds=max(20.0, min(180.0, args.leg_timeout / 2))))
+
+        def leg(name, leg_ctl):
+            nonlocal ctl
+            ctl = leg_ctl
+            try:
+                # peer: the model's own small collectives (velocity gather among same-frame ranks, the final frame gather) ride on gloo,
+                # so the leg makes no RCCL call at all; rccl: everything on the nccl WORLD
+                r = run_leg(name, leg_ctl if name == "peer" else dist.group.WORLD)
+                torch.cuda.synchronize(dev)
+                return r
+            finally:
+                ctl = ctl_main
 
         def describe(r):
             d = {"ms_per_step": round(r["elapsed"] / args.steps * 1e3, 2),
@@ -728,9 +963,17 @@ def main():
                 d["flags_fine_grained"] = bool(r["flags_fine_grained"])
             return d
 
-        legs, exchange_ab = run_exchange_legs(order, leg, ctl, rank, args.leg_timeout, on_watchdog, describe)
+        legs, exchange_ab = run_exchange_legs(order, leg, rank, world, args.leg_timeout, on_watchdog, describe, store=store, make_ctl=make_ctl)
+        for n in skipped:
+            exchange_ab[n] = {"ok": False, "skipped": True,
+                              "error": f"failed the pre-flight, no leg was run: {preflight[n].get('error', 'see exchange_ab.preflight')}"}
+        if preflight is not None:
+            exchange_ab["preflight"] = preflight
         if not legs:
-            raise SystemExit(f"bench.py: every exchange leg failed: {exchange_ab}")
+            if rank == 0:
+                print(json.dumps({"error": "bench.py: every exchange leg failed", "metric": f"denoise-steps/sec ({T}f x {N}tok)", "value": None,
+                                  "n_gpus": world, "exchange_ab": exchange_ab}), flush=True)
+            raise SystemExit(3)
         best = min(legs.values(), key=lambda r: r["elapsed"])
 
     # ---- N > 1: is the sharded result the single-rank result?  Rank 0 re-runs the SAME warmup + steps steps on an unsharded engine (its

@@ -98,13 +98,18 @@ def test_copy_engine_exchange_on_real_ranks(world):
     _run(world, env_extra={"ACTIONMESH_AMD_EXCHANGE": "peer"})          # the same back-end under HipDenoiser + RCCL control plane
 
 
-def _bench(world, extra=()):
-    """bench.py itself, as the driver launches it (torch.distributed.run for N > 1), with every rank on ONE device."""
+def _bench(world, extra=(), bare=False):
+    """bench.py itself, as the driver launches it (torch.distributed.run for N > 1), with every rank on ONE device.  `bare`: N > 1
+    WITHOUT a launcher around it - bench.py re-executes itself under torch.distributed.run (round 6)."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--shape", "small", "--no-cpu-baseline", *extra]
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    elif bare:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args, "--same-device"]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), *args, "--same-device"]
@@ -175,3 +180,35 @@ def test_bench_pure_frame_sharding():
     d = _bench(4, ("--cfg-parallel", "0"))
     assert d["config"]["parallelism"] == "cfg-branch x1 * frame-shard x4"
     assert d["fingerprint_ok"] is True and d["exchange_ab"]["peer"]["ok"] is True
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_launches_itself_and_preflights(world):
+    """`python bench.py --gpus N` with NO launcher around it re-executes itself under torch.distributed.run, the
+    ONE JSON line is the last line of stdout and the exit code is 0; in front of the legs every rank ran the seconds-long pre-flight of
+    the exchange back-end in a killable child process and the verdict is in `exchange_ab.preflight` (sharded vs single-rank latents of
+    the pre-flight problem within the stated 3e-2)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _bench(world, bare=True)
+    assert d["launcher"]["self_launched"] is True and d["launcher"]["attempts"][0]["returncode"] == 0
+    assert d["launcher"]["attempts"][0]["argv"][:2] == ["--gpus", str(world)] and "torch.distributed.run" in d["launcher"]["command"]
+    assert d["n_gpus"] == world and d["value"] > 0 and d["fingerprint_ok"] is True
+    pf = d["exchange_ab"]["preflight"]["peer"]
+    assert pf["ok"] is True and pf["rel_l2_vs_single_rank"] <= 3e-2 and pf["seconds"] < 90, pf
+    assert d["exchange_ab"]["peer"]["ok"] is True
+
+
+def test_bench_preflight_keeps_a_dead_backend_from_the_legs():
+    """`--exchange ab` with every rank on one device: RCCL cannot run there - the pre-flight says so in seconds, no leg is spent on it,
+    the copy-engine leg is the result."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _bench(4, ("--exchange", "ab"))
+    ab = d["exchange_ab"]
+    assert ab["preflight"]["rccl"]["ok"] is False and ab["preflight"]["peer"]["ok"] is True
+    assert ab["rccl"]["ok"] is False and ab["rccl"].get("skipped") is True and "RCCL refuses two ranks" in ab["rccl"]["error"]
+    assert ab["peer"]["ok"] is True and d["value"] > 0
+    # and with the pre-flight off the leg itself fails and the fallback is what carries the line (the round-5 behaviour)
+    d = _bench(4, ("--exchange", "ab", "--no-preflight"))
+    assert d["exchange_ab"]["rccl"]["ok"] is False and "skipped" not in d["exchange_ab"]["rccl"] and d["exchange_ab"]["peer"]["ok"] is True

@@ -379,40 +379,55 @@ def test_sampler_keeps_latents_sharded_across_steps(world, cfg_parallel, split):
 def _legs_worker(rank, world, port, outdir, scenario):
     import json
     import time
+    from datetime import timedelta
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from actionmesh_amd.sharding import run_exchange_legs
-    ctl = dist.new_group(backend="gloo")
 
     def write(payload):
         with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
             json.dump(payload, f)
 
-    def run_leg(name):
+    def run_leg(name, ctl):
         if scenario == "rccl_raises_on_rank1" and name == "rccl" and rank == 1:
             raise RuntimeError("ncclSystemError: stand-in failure")
         if scenario == "second_leg_hangs" and name == "peer":
             time.sleep(600)                               # a collective that never returns
+        if scenario == "first_leg_hangs" and name == "rccl":
+            time.sleep(600)
+        if scenario == "rank1_raises_mid_leg" and name == "rccl":
+            # rank 1 leaves the leg while rank 0 is inside the leg's OWN collectives (bench's barrier + MAX all-reduce on
+            # the control group): the verdict must not pair with them, and rank 0 must come back out (the group's timeout)
+            if rank == 1:
+                raise RuntimeError("out of memory on one device: stand-in failure")
+            dist.barrier(group=ctl)
+            t = torch.tensor([1.0]); dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+        if name == "peer":                                # the next leg's collectives work on ITS fresh group whatever happened before
+            t = torch.tensor([float(rank)]); dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
+            assert float(t) == world - 1
         return {"elapsed": 1.0 + (0.5 if name == "rccl" else 0.0) + 0.01 * rank}
 
     def on_watchdog(name, legs, report):
         report[name] = {"ok": False, "error": "watchdog"}
         write({"watchdog": name, "legs": sorted(legs), "report": report})
-        os._exit(0)
+        os._exit(0 if legs else 3)
 
-    legs, report = run_exchange_legs(["rccl", "peer"], run_leg, ctl, rank, 3.0, on_watchdog,
-                                     describe=lambda r: {"ms_per_step": r["elapsed"] * 1e3})
+    legs, report = run_exchange_legs(["rccl", "peer"], run_leg, rank, world, 8.0 if scenario == "rank1_raises_mid_leg" else 3.0, on_watchdog,
+                                     describe=lambda r: {"ms_per_step": r["elapsed"] * 1e3},
+                                     make_ctl=lambda: dist.new_group(backend="gloo", timeout=timedelta(seconds=3)))
     write({"legs": sorted(legs), "report": report})
-    dist.destroy_process_group()
+    os._exit(0)          # (a group whose collective timed out does not always tear down cleanly; the verdict is on disk)
 
 
-@pytest.mark.parametrize("scenario", ["both_ok", "rccl_raises_on_rank1", "second_leg_hangs"])
+@pytest.mark.parametrize("scenario", ["both_ok", "rccl_raises_on_rank1", "second_leg_hangs", "first_leg_hangs", "rank1_raises_mid_leg"])
 def test_exchange_ab_fallback_and_watchdog(tmp_path, scenario):
     """sharding.run_exchange_legs between two gloo processes with stand-in legs: (a) both complete - both reported; (b) the RCCL leg
     raises on ONE rank - every rank agrees it failed (error text where it happened, "failed on another rank" elsewhere) and the
     copy-engine leg runs and is the result; (c) the second leg never returns - the watchdog of every rank reports the first leg and
-    leaves with exit code 0."""
+    leaves with exit code 0; (d) the FIRST leg never returns - the watchdog is armed there too and leaves with exit code 3 (round 6);
+    (e) one rank raises while the other is inside the leg's own control-plane collectives - the verdicts travel on the store, the
+    stuck rank's collective times out, both agree and the next leg runs on a fresh group."""
     import json
     ctxm = mp.get_context("spawn")
     port = 29400 + (os.getpid() * 11 + len(scenario) * 17) % 500
@@ -421,7 +436,7 @@ def test_exchange_ab_fallback_and_watchdog(tmp_path, scenario):
         p.start()
     for p in procs:
         p.join(120)
-        assert p.exitcode == 0, p.exitcode
+        assert p.exitcode == (3 if scenario == "first_leg_hangs" else 0), p.exitcode
     out = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
     if scenario == "both_ok":
         for o in out:
@@ -430,8 +445,51 @@ def test_exchange_ab_fallback_and_watchdog(tmp_path, scenario):
     elif scenario == "rccl_raises_on_rank1":
         for o in out:
             assert o["legs"] == ["peer"] and o["report"]["peer"]["ok"] and not o["report"]["rccl"]["ok"]
-        assert "failed on another rank" in out[0]["report"]["rccl"]["error"]
+        assert "failed on another rank" in out[0]["report"]["rccl"]["error"] and "stand-in failure" in out[0]["report"]["rccl"]["error"]
         assert "stand-in failure" in out[1]["report"]["rccl"]["error"]
+    elif scenario == "rank1_raises_mid_leg":
+        for o in out:
+            assert o["legs"] == ["peer"] and o["report"]["peer"]["ok"] and not o["report"]["rccl"]["ok"], o
+        assert "stand-in failure" in out[1]["report"]["rccl"]["error"]
+        assert out[0]["report"]["rccl"]["failed_ranks"] == [0, 1]          # rank 0's own collective timed out: it failed there too
+    elif scenario == "first_leg_hangs":
+        for o in out:
+            assert o["watchdog"] == "rccl" and o["legs"] == [] and not o["report"]["rccl"]["ok"]
     else:
         for o in out:
             assert o["watchdog"] == "peer" and o["legs"] == ["rccl"] and o["report"]["rccl"]["ok"] and not o["report"]["peer"]["ok"]
+
+
+def test_bench_self_launch_argument_passing_on_cpu():
+    """`python bench.py --gpus N` without a launcher, on a box with no GPU: (a) fewer devices than ranks - ONE JSON
+    error line, exit code 2, nothing launched; (b) --same-device (no device count to check): the command re-executes itself under
+    torch.distributed.run with the SAME arguments, the ranks die here for want of a GPU, and the launcher still ends with one JSON line
+    (the attempts with their arguments and exit codes) and a non-zero exit code."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour of the launcher")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 2 and rec["value"] is None and rec["visible_devices"] == 0 and "--gpus 2" in rec["error"]
+    argv = ["--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1", "--shape", "small", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1 and lines[0] == r.stdout.strip().splitlines()[-1], r.stdout[-500:]
+    rec = json.loads(lines[0])
+    att = rec["launcher"]["attempts"]
+    assert rec["launcher"]["self_launched"] and len(att) == 1 and att[0]["argv"] == argv and att[0]["returncode"] != 0
+
+
+def test_launcher_command_is_the_drivers():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cmd = bench.launcher_argv(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, 29511)
+    assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29511"]
+    assert cmd[9].endswith("bench.py") and cmd[10:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.preflight_plan(8, 1) == 8 and bench.preflight_plan(8, 0) == 16 and bench.preflight_plan(2, 1) == 4

@@ -119,4 +119,16 @@ print('$t:', {k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac
     done
     ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
+  r06a)   # round 6, first contact: the self-launching bench + pre-flight on one device, then the GEMM tables the model
+          # really launches (fused epilogues) at both architectures, and a baseline bench line of the unchanged kernels
+    PT="python -m pytest -q -m gpu -v --timeout=600 --durations=10"
+    timeout 1200 $PT tests/test_multi_gpu.py -k "bench" 2>&1 | grep -v "^$" | grep -vE "PASSED" | tail -30 | cut -c1-400 | tee gpurun_out/r06a_mgpu.txt
+    for sh in headline nominal; do
+      python tools/kernel_bench.py --shape $sh --only gemm,fused --product-only --blas --reps 20 2>&1 | grep -E "^gemm|^qkv|^cross" | tee gpurun_out/r06a_gemm_$sh.txt
+    done
+    timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r06a_bench.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r06a_bench.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'])"
+    ;;
 esac

@@ -118,7 +118,6 @@ import json; d=json.load(open('gpurun_out/r05f_bench_$t.json')); r=d['roofline']
 print('$t:', {k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], r.get('energy_j'), r.get('effective_clock_ghz'), r.get('pipe_busy'), d['latents_fingerprint']['sample'][:3])"
     done
     ;;
-  *) echo "unknown entry $NAME"; exit 2 ;;
   r06a)   # round 6, first contact: the self-launching bench + pre-flight on one device, then the GEMM tables the model
           # really launches (fused epilogues) at both architectures, and a baseline bench line of the unchanged kernels
     PT="python -m pytest -q -m gpu -v --timeout=600 --durations=10"
@@ -131,4 +130,5 @@ print('$t:', {k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac
 import json; d=json.load(open('gpurun_out/r06a_bench.json')); r=d['roofline']
 print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'])"
     ;;
+  *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(am_gemm_args p, int t
         const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(&Cs[row * CS_LD + c8 + 4]);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (p.ln_stats) {                                           // folded LayerNorm: same two FMAs as the 256x256 kernel
-          const f32x2_t st = *reinterpret_cast<const f32x2_t*>(p.ln_stats + 2 * (int64_t)gmr);
+          // the statistics belong to the A row this output row was computed from (norm_out -> drop the time token -> proj_out reads the
+          // residual stream through a row map, temporal_denoiser.py:239-242)
+          const f32x2_t st = *reinterpret_cast<const f32x2_t*>(p.ln_stats + 2 * map_row(gmr, p.a_G, p.a_gs, p.a_off));
           const float nm = -st[0] * st[1];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = rbf(fmaf(v[e], st[1], fmaf(nm, cs[e], bv[e])));
@@ -444,7 +446,8 @@ __device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p
                                                            int tid, int m0, int n0) {
   const int k16 = tid & 31, r16 = tid >> 5;
   const int half = k16 >> 4, sub = k16 & 15;
-  {
+  const bool abl_noqk = (p.act & 0x800) != 0, abl_nov = (p.act & 0x1000) != 0;      // timing ablations (tools/kernel_bench.py --ablate-gemm)
+  if (!abl_noqk) {
     const int pi = (n0 >> 7) + half;                           // (head, part) slice of this thread's 128-column half
     const int head = pi / hp.nparts, part = pi - head * hp.nparts;
     const int kind = (n0 + half * 128 < p.N) ? hp.kinds[part] : 3;
@@ -457,10 +460,26 @@ __device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p
       const int s_pad = kind == 0 ? hp.sq_pad : hp.sk_pad;
       const unsigned char* su = stage + r16 * 512 + ((k16 ^ (r16 >> 1)) << 4);
       const bool odd = r16 & 1;
-#pragma unroll 2
-      for (int pass = 0; pass < 16; ++pass) {
+      // Round 6: a 256-row tile lies in at most TWO frames and TWO sequences when both are at least 256 rows long (every reference
+      // shape: a frame is N + 1 >= 2049 rows).  The frame's RoPE angles and the sequence's output base are then fetched / divided
+      // ONCE per tile - wave-uniform scalars and 4 x 16 bytes per thread in front of the loop - instead of two global loads and two
+      // integer divisions per row (32 exposed loads per thread, the whole difference between this epilogue and the plain C store).
+      const bool two = hp.rows_per_frame >= B2 && hp.seq_len >= B2;
+      const int frame0 = m0 / hp.rows_per_frame, seq0 = m0 / hp.seq_len;
+      const int fb = (frame0 + 1) * hp.rows_per_frame, sb = (seq0 + 1) * hp.seq_len;      // first row of the next frame / sequence
+      f32x4_t cs0 = {1.f, 1.f, 1.f, 1.f}, sn0 = {0.f, 0.f, 0.f, 0.f}, cs1 = cs0, sn1 = sn0;
+      if (hp.rope_cos && two) {
+        const int frame1 = fb < p.M ? frame0 + 1 : frame0;     // (the tile's rows past p.M are never written)
+        cs0 = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame0 * 64 + sub * 4);
+        sn0 = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame0 * 64 + sub * 4);
+        cs1 = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame1 * 64 + sub * 4);
+        sn1 = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame1 * 64 + sub * 4);
+      }
+      bf16_t* const out0 = out + (((int64_t)seq0 * hp.heads + head) * s_pad - (int64_t)seq0 * hp.seq_len) * 128 + sub * 8;     // + gm * 128
+      bf16_t* const out1 = out0 + ((int64_t)hp.heads * s_pad - hp.seq_len) * 128;
+      auto one_row = [&](int pass) __attribute__((always_inline)) {
         const int gm = m0 + pass * 16 + r16;
-        if (gm >= p.M) continue;
+        if (gm >= p.M) return;
         u32x4_t u = *reinterpret_cast<const u32x4_t*>(su + pass * 8192);
         if (odd) u = u32x4_t{u[2], u[3], u[0], u[1]};
         float v[8];
@@ -482,20 +501,39 @@ __device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p
           for (int e = 0; e < 8; ++e) v[e] = (v[e] * r) * wv[e];
         }
         if (hp.rope_cos) {
-          const int frame = gm / hp.rows_per_frame;
-          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame * 64 + sub * 4);
-          const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame * 64 + sub * 4);
+          f32x4_t cs, sn;
+          if (two) {
+            const bool nx = gm >= fb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] = nx ? cs1[e] : cs0[e]; sn[e] = nx ? sn1[e] : sn0[e]; }
+          } else {
+            const int frame = gm / hp.rows_per_frame;
+            cs = *reinterpret_cast<const f32x4_t*>(hp.rope_cos + (int64_t)frame * 64 + sub * 4);
+            sn = *reinterpret_cast<const f32x4_t*>(hp.rope_sin + (int64_t)frame * 64 + sub * 4);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) rope_rotate(v[2 * e], v[2 * e + 1], cs[e], sn[e]);    // rotary_embedding.py:116-122
         }
         u32x4_t w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-        const int seq = gm / hp.seq_len, sq = gm - seq * hp.seq_len;
-        *reinterpret_cast<u32x4_t*>(out + (((int64_t)seq * hp.heads + head) * s_pad + sq) * 128 + sub * 8) = w;
+        if (two) {
+          *reinterpret_cast<u32x4_t*>((gm >= sb ? out1 : out0) + (int64_t)gm * 128) = w;
+        } else {
+          const int seq = gm / hp.seq_len, sq = gm - seq * hp.seq_len;
+          *reinterpret_cast<u32x4_t*>(out + (((int64_t)seq * hp.heads + head) * s_pad + sq) * 128 + sub * 8) = w;
+        }
+      };
+      if (two) {
+#pragma unroll 4
+        for (int pass = 0; pass < 16; ++pass) one_row(pass);
+      } else {
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) one_row(pass);
       }
     }
   }
+  if (abl_nov) return;
   // ---- V slice (at most one of the two halves for the q | k | v interleave): transposed read-back
 #pragma unroll
   for (int h2 = 0; h2 < 2; ++h2) {
@@ -1089,18 +1127,31 @@ static const uint16_t* gelu_table(hipStream_t st) {
   static uint16_t* tab[64];
   static int state[64];              // 0 unknown, 1 ready, 2 off
   static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  // the table belongs to the device that OWNS the stream, which need not be the calling thread's current device; the
+  // null stream has no owner to ask: the current device then
+  int dev = 0, cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  dev = cur;
+  if (st != nullptr && hipStreamGetDevice(st, &dev) != hipSuccess) { (void)hipGetLastError(); dev = cur; }
+  if (dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
   if (state[dev] == 0) {
     const char* e = getenv("ACTIONMESH_AMD_GELU_TABLE");
     if (e && e[0] == '0') { state[dev] = 2; return nullptr; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    // a failure here (allocation, launch) is NOT latched: this call runs the arithmetic epilogue - same bits - and the next one tries
+    // again; only the environment switch turns the table off for the life of the process
+    if (dev != cur && hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     uint16_t* t = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&t), GT_BYTES) != hipSuccess) { (void)hipGetLastError(); state[dev] = 2; return nullptr; }
-    hipLaunchKernelGGL(gelu_table_kernel, dim3(ceil_div(GT_ENTRIES, 256)), dim3(256), 0, st, t);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(t); state[dev] = 2; return nullptr; }
+    bool ok = hipMalloc(reinterpret_cast<void**>(&t), GT_BYTES) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(gelu_table_kernel, dim3(ceil_div(GT_ENTRIES, 256)), dim3(256), 0, st, t);
+      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+      if (!ok) (void)hipFree(t);
+    }
+    if (dev != cur) (void)hipSetDevice(cur);
+    if (!ok) { (void)hipGetLastError(); return nullptr; }
     tab[dev] = t;                    // synchronised: every stream of the device may read it from here on
     state[dev] = 1;
   }
@@ -1139,7 +1190,9 @@ extern "C" int am_gemm_bf16(const am_gemm_args* a, void* stream) {
            "am_gemm_bf16: operands must be 16-byte aligned");
   if (a->ln_stats) {
     AM_CHECK(a->ln_colsum != nullptr, "am_gemm_bf16: ln_stats without ln_colsum");
-    AM_CHECK(a->A2 == nullptr && a->a_G == 0, "am_gemm_bf16: a folded LayerNorm needs one A operand with the identity row map");
+    AM_CHECK(a->A2 == nullptr, "am_gemm_bf16: a folded LayerNorm needs one A operand");
+    // a row map on A is honoured by the 128x128 kernel only (ln_stats is indexed by the mapped A row): narrow linears such as proj_out
+    AM_CHECK(a->a_G == 0 || a->N < 256 || (a->act & 0x100), "am_gemm_bf16: a folded LayerNorm over a row-mapped A needs N < 256 (the 128x128 kernel)");
     AM_CHECK(!(a->act & 0x200), "am_gemm_bf16: the round-1 lockstep kernel has no folded-LayerNorm epilogue");
     AM_CHECK(((uintptr_t)a->ln_stats % 8 == 0) && ((uintptr_t)a->ln_colsum % 16 == 0) && (a->bias == nullptr || (uintptr_t)a->bias % 16 == 0) &&
              a->N % 4 == 0, "am_gemm_bf16: ln_stats / ln_colsum / bias misaligned");
@@ -1251,7 +1304,7 @@ extern "C" int am_gemm_headpost_bf16(const am_gemm_args* g, const am_headpost_ar
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
   });
   am_gemm_args args = *g;
-  args.act = 0;
+  args.act = g->act & 0x1800;                 // the epilogue's timing ablations (tools/kernel_bench.py); 0 on the product path
   const int m_main = tail_split ? args.M - rem : args.M;
   const int tiles_m = ceil_div(m_main, B2), tiles_n = ceil_div(args.N, B2);
   {

@@ -45,6 +45,8 @@ struct am_model {
   std::vector<am_layer> layers;
   bf16_t *w_t1 = nullptr, *w_t2 = nullptr, *w_in = nullptr, *w_out = nullptr;
   float *b_t1 = nullptr, *b_t2 = nullptr, *b_in = nullptr, *b_out = nullptr, *ln_o_w = nullptr, *ln_o_b = nullptr;
+  bf16_t* wf_out = nullptr;                     // proj_out with norm_out folded in (round 6; temporal_denoiser.py:239-242)
+  float *cs_out = nullptr, *d_out = nullptr;
   std::set<std::string> expected, loaded;
   std::vector<void*> allocs;
   float* stage_f32 = nullptr;
@@ -244,11 +246,20 @@ int gemm(hipStream_t st, const bf16_t* A, int lda, const bf16_t* W, int ldw, con
 
 int prepare_folds(am_model* m, hipStream_t st) {
   const int C = m->C, F = m->F;
+  {   // the synchronisation below is illegal inside a stream capture (it would invalidate it): a caller that captures the split API
+      // must run one eager forward after am_load_weights first (am_denoise_forward_graph does) - say so instead
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      AM_FAIL(AM_ERR_STATE, "%s", "the folded LayerNorm weights are built (and synchronised) by the first forward after am_load_weights: "
+                                  "run one forward eagerly before capturing this stream");
+    (void)hipGetLastError();
+  }
   for (am_layer& l : m->layers) {
     AM_TRY(am_ln_fold_weight(l.w_qkv, l.ln_s_w, l.ln_s_b, nullptr, l.wf_qkv, l.cs_qkv, l.d_qkv, 3 * C, C, st));
     AM_TRY(am_ln_fold_weight(l.w_xq, l.ln_x_w, l.ln_x_b, nullptr, l.wf_xq, l.cs_xq, l.d_xq, C, C, st));
     AM_TRY(am_ln_fold_weight(l.w_ff1, l.ln_f_w, l.ln_f_b, l.b_ff1, l.wf_ff1, l.cs_ff1, l.d_ff1, F, C, st));
   }
+  AM_TRY(am_ln_fold_weight(m->w_out, m->ln_o_w, m->ln_o_b, m->b_out, m->wf_out, m->cs_out, m->d_out, m->Din, C, st));
   // once per weight load, never inside a capture: the folded weights are read by every later forward on WHATEVER stream it is
   // launched on (an eager forward on another torch stream, the graph stream after an eager call) - make them visible to all of
   // them before the flag says so (they used to be ordered only with the stream of the first forward)
@@ -301,6 +312,7 @@ extern "C" int am_create(const am_config* cfg, am_handle* out) {
   A_(dev_alloc_t(m, &m->w_in, C * Din)); A_(dev_alloc_t(m, &m->b_in, C));
   A_(dev_alloc_t(m, &m->w_out, Din * C)); A_(dev_alloc_t(m, &m->b_out, Din));
   A_(dev_alloc_t(m, &m->ln_o_w, C)); A_(dev_alloc_t(m, &m->ln_o_b, C));
+  A_(dev_alloc_t(m, &m->wf_out, Din * C)); A_(dev_alloc_t(m, &m->cs_out, Din)); A_(dev_alloc_t(m, &m->d_out, Din));
 
   // workspace bounds
   m->maxB = cfg->max_batch; m->maxT = cfg->max_frames_local; m->maxN = cfg->max_tokens; m->maxS = cfg->max_ctx_tokens;
@@ -840,8 +852,8 @@ extern "C" int am_layer_post_attn(am_handle h, int i, void* stream) {
   if (i < h->NL / 2) dst = h->skip[h->skip_top++];     // temporal_denoiser.py:231-232 (kept, not copied)
   {
     // the next reader of the row statistics is the next block's norm_s_attn - unless that block starts with its skip linear + norm_skip
-    // (which writes its own) or there is no next block (norm_out runs as a LayerNorm kernel in front of the 64-column proj_out)
-    const bool want = h->ln_fold && i + 1 < h->NL && !h->has_skip(i + 1);
+    // (which writes its own); behind the last block the reader is norm_out, folded into proj_out (am_forward_end, round 6)
+    const bool want = h->ln_fold && (i + 1 >= h->NL || !h->has_skip(i + 1));
     am_gemm_args g2 = {};
     g2.A1 = h->ffh; g2.lda1 = F; g2.K1 = F; g2.W = l.w_ff2; g2.ldw = F; g2.bias = l.b_ff2; g2.residual = h->hwork;
     g2.C = dst; g2.ldc = C; g2.M = (int)R; g2.N = C; g2.K = F;
@@ -862,10 +874,22 @@ extern "C" int am_forward_end(am_handle h, uint16_t* v_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int C = h->C;
   // norm_out -> drop the time token -> proj_out (temporal_denoiser.py:239-242)
-  AM_TRY(am_layernorm_bf16(h->hsrc, h->z, h->ln_o_w, h->ln_o_b, h->R, C, 1e-5f, st));
-  TR(24, 0, h->z, (size_t)h->R * C * 2);
-  AM_TRY(gemm(st, h->z, C, h->w_out, C, h->b_out, nullptr, v_out, h->Din, (int64_t)h->B * h->T * h->N, h->Din, C, 0,
-              nullptr, 0, 0, /*aG*/ h->N, /*ags*/ h->L, /*aoff*/ 1));
+  if (h->ln_fold && h->NL > 0) {
+    // round 6: norm_out inside proj_out like the three LayerNorms of a block - the last ff.net.2 left the row statistics of the
+    // residual stream (am_layer_post_attn: `want`), proj_out reads the un-normalised rows through its row map (time token dropped)
+    // and evaluates rstd (x W'^T - mean colsum) + d in its epilogue; the LayerNorm kernel and its R x C round trip are gone
+    am_gemm_args g = {};
+    g.A1 = h->hsrc; g.lda1 = C; g.K1 = C; g.W = h->wf_out; g.ldw = C; g.bias = h->d_out; g.C = v_out; g.ldc = h->Din;
+    g.M = (int)((int64_t)h->B * h->T * h->N); g.N = h->Din; g.K = C;
+    g.a_G = h->N; g.a_gs = h->L; g.a_off = 1;
+    g.ln_stats = h->ln_stats; g.ln_colsum = h->cs_out;
+    AM_TRY(am_gemm_bf16(&g, st));
+  } else {
+    AM_TRY(am_layernorm_bf16(h->hsrc, h->z, h->ln_o_w, h->ln_o_b, h->R, C, 1e-5f, st));
+    TR(24, 0, h->z, (size_t)h->R * C * 2);
+    AM_TRY(gemm(st, h->z, C, h->w_out, C, h->b_out, nullptr, v_out, h->Din, (int64_t)h->B * h->T * h->N, h->Din, C, 0,
+                nullptr, 0, 0, /*aG*/ h->N, /*ags*/ h->L, /*aoff*/ 1));
+  }
   TR(25, 0, v_out, (size_t)h->B * h->T * h->N * h->Din * 2);
   h->in_forward = false;
   return AM_OK;

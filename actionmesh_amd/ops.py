@@ -213,7 +213,7 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
                    rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, eps: float = 1e-6,
                    out_q: Optional[torch.Tensor] = None, out_k: Optional[torch.Tensor] = None,
                    out_vt: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None,
-                   bias: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                   bias: Optional[torch.Tensor] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, ablate: int = 0):
     """am_gemm_headpost_bf16: (a @ w.T) -> head split / qk-RMSNorm / RoPE / attention layouts in ONE launch; the arguments of `gemm`
     (no bias, no activation) and of `head_post`.  `x` (rows, N) is the linear's output buffer the un-fused pair would use (only the
     tile grid's remainder rows are written to it).  Returns (Q, K, Vt) like head_post."""
@@ -231,6 +231,7 @@ def gemm_head_post(a: torch.Tensor, w: torch.Tensor, heads: int, kinds: Sequence
     g.W = w.data_ptr(); g.ldw = w.stride(0)
     g.C = x.data_ptr(); g.ldc = x.stride(0)
     g.M, g.N, g.K = rows, N, K
+    g.act = ablate & 0x1800      # timing ablations of the fused epilogue (0x800: no Q / K rows, 0x1000: no V^T read-back); never on the product path
     if bias is not None:
         g.bias = _need(bias, torch.float32, "bias").data_ptr()
     if ln is not None:       # LayerNorm folded into the projection (gemm's `ln`)

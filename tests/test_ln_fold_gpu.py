@@ -243,3 +243,32 @@ def test_fold_under_large_row_means_and_outlier_channels(dtype, shift, outlier):
           f"un-folded pair {e_pair:.3e}, folded vs pair {rel(folded, pair):.3e}")
     assert bool(torch.isfinite(folded.float()).all())
     assert e_fold <= 1.05 * e_pair and e_fold < 1.5 * eps16, (e_fold, e_pair)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_norm_out_folded_into_proj_out_through_the_row_map(dtype):
+    """Round 6 (temporal_denoiser.py:239-242): norm_out -> drop each frame's time token -> proj_out (C -> 64) as
+    ONE narrow linear that reads the un-normalised residual stream through its row map, with the statistics indexed by the MAPPED row.
+    Against the un-folded pair (LayerNorm kernel, then the row-mapped linear) and the fp32 statement."""
+    frames, N, C, Din = 6, 333, 1024, 64
+    L = N + 1
+    x = rnd(frames * L, C, seed=21, dtype=dtype, scale=1.9, shift=-0.7)
+    w = rnd(Din, C, seed=22, dtype=dtype, scale=C ** -0.5)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    beta = torch.randn(C, device=DEV) * 0.2
+    bias = torch.randn(Din, device=DEV).to(dtype).float()
+    wf, colsum, d = ops.ln_fold_weight(w, gamma, beta, bias)
+    st = ops.row_stats(x)
+    amap = (N, L, 1)
+    out = ops.gemm(x, wf, bias=d, ln=(st, colsum), a_map=amap, M=frames * N)
+    unfolded = ops.gemm(ops.layernorm(x, gamma, beta), w, bias=bias, a_map=amap, M=frames * N)
+    keep = x.view(frames, L, C)[:, 1:].reshape(-1, C)
+    ref = ln_ref(keep, gamma, beta) @ w.float().T + bias
+    e_fold, e_pair = rel(out, ref), rel(unfolded, ref)
+    eps16 = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert e_fold < 0.75 * eps16 and e_fold <= e_pair * 1.02, (e_fold, e_pair)
+    # the statistics really are the mapped rows': shifting every time-token row (never read) changes nothing, bit for bit
+    x2 = x.clone().view(frames, L, C)
+    x2[:, 0] += 100.0
+    x2 = x2.view(-1, C)
+    assert torch.equal(ops.gemm(x2, wf, bias=d, ln=(ops.row_stats(x2), colsum), a_map=amap, M=frames * N), out)

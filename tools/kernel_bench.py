@@ -129,6 +129,18 @@ def main():
         two = timeit(lambda: ops.head_post(ops.gemm(z, wqkv, out=x), H, (0, 1, 2), T * L_, L_, w_q=nq, w_k=nk, rope=rope, out_q=q_, out_k=k_, out_vt=v_), a.reps)
         one = timeit(lambda: ops.gemm_head_post(z, wqkv, H, (0, 1, 2), T * L_, L_, w_q=nq, w_k=nk, rope=rope, out_q=q_, out_k=k_, out_vt=v_, x=x), a.reps)
         print(f"qkv linear + head split  R={R} 3C={3 * C}: two launches {two:8.3f} ms, fused {one:8.3f} ms")
+        # the launch the MODEL makes (round 6): LayerNorm folded in (statistics + column sums + d), beside the plain linear of the same
+        # shape and the epilogue's timing ablations (no Q / K rows, no V^T read-back, neither = main loop + staging pass only)
+        stats = torch.stack([torch.zeros(R, device=dev), torch.ones(R, device=dev)], 1).contiguous()
+        colsum = wqkv.float().sum(1).contiguous(); dvec = torch.zeros(3 * C, device=dev)
+        kw = dict(w_q=nq, w_k=nk, rope=rope, out_q=q_, out_k=k_, out_vt=v_, x=x)
+        plain = timeit(lambda: ops.gemm(z, wqkv, out=x), a.reps)
+        fold = timeit(lambda: ops.gemm_head_post(z, wqkv, H, (0, 1, 2), T * L_, L_, bias=dvec, ln=(stats, colsum), **kw), a.reps)
+        print(f"qkv in-model (LN fold + head split + qk-norm + RoPE) R={R} 3C={3 * C}: {fold:8.3f} ms  {2.0 * R * 3 * C * C / fold / 1e9:7.1f} TFLOP/s"
+              f"   | plain linear {plain:8.3f} ms, fused without the fold {one:8.3f} ms")
+        for ab, nm in ((0x800, "no Q / K rows"), (0x1000, "no V^T read-back"), (0x1800, "neither (main loop + staging)")):
+            ms = timeit(lambda: ops.gemm_head_post(z, wqkv, H, (0, 1, 2), T * L_, L_, bias=dvec, ln=(stats, colsum), ablate=ab, **kw), a.reps)
+            print(f"  qkv in-model ablation {nm:30s}: {ms:8.3f} ms")
         wxq = rnd(C, C)
         xq = torch.empty((R, C), dtype=torch.bfloat16, device=dev)
         qx, _, _ = ops.head_post(ops.gemm(z, wxq, out=xq), H, (0,), L_, L_, w_q=nq)

@@ -130,5 +130,16 @@ print('$t:', {k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac
 import json; d=json.load(open('gpurun_out/r06a_bench.json')); r=d['roofline']
 print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'])"
     ;;
+  r06b)   # the hoisted fused-QKV epilogue + norm_out fold: kernel / fold / model parity tests, the in-model QKV launch with its ablations, a bench line
+    PT="python -m pytest -q -m gpu --timeout=600 --durations=8"
+    timeout 1500 $PT tests/test_kernels_gpu.py tests/test_ln_fold_gpu.py tests/test_denoiser_gpu.py tests/test_f16_gpu.py -x 2>&1 | grep -v "^$" | tail -25 | cut -c1-300 | tee gpurun_out/r06b_tests.txt
+    for sh in headline nominal; do
+      python tools/kernel_bench.py --shape $sh --only fused --reps 20 2>&1 | grep -E "qkv|cross" | tee gpurun_out/r06b_fused_$sh.txt
+    done
+    timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r06b_bench.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r06b_bench.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'], d['latents_fingerprint'])"
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

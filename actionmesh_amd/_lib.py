@@ -128,6 +128,7 @@ SYMBOLS = {
     "am_step_flops": (C.c_double, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "am_gemm_bf16": (C.c_int, [C.POINTER(AmGemmArgs), _P]),
     "am_layernorm_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "am_add_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "am_row_stats_bf16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "am_row_stats_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, C.c_float, _P]),
     "am_layernorm_stats_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P, _P]),

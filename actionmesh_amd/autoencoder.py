@@ -15,8 +15,14 @@ sequence is kept frame-major exactly like Stage I's (`[alpha token | N latent to
 the Stage-I kernels apply unchanged (head_post without qk-norm, 4x64 attention over the T*L tokens), and the
 cross-attention does not care about key order.  The rows of the projected latents are written once and re-used by all
 targets; only the T alpha rows change between targets.
-Precision: 16-bit storage / fp32 accumulation like Stage I (the reference runs the self-attention stack under cuda
-autocast and the query side in fp32); tolerance stated in tests/test_autoencoder.py.
+Precision: 16-bit operands / fp32 accumulation like Stage I, and - round 6, `residual_fp32=True`, the default - an **fp32 residual
+stream** as in the reference: its torch.cat of the 16-bit projected latents with the fp32 alpha embedding promotes the stream to
+fp32 (temporal_autoencoder.py:258), every `h + branch` under autocast then adds a 16-bit linear output into fp32, FP32LayerNorm reads
+fp32, and the query side / cross-attention block run with autocast off (:236, :265).  Here: the residual streams of the self-attention
+stack and of the query block are fp32 tensors; one kernel per branch adds the branch's 16-bit output into it and emits the next
+LayerNorm's 16-bit output (am_add_layernorm_f32).  The cross-attention block's linears and attention stay 16-bit MFMA (there is no
+fp32 matrix path in the library); `residual_fp32=False` is the round-5 all-16-bit stream.  Tolerances: tests/test_autoencoder.py.
+float16 range: activations above 65504 overflow in IEEE half; a float16 forward whose result is not finite raises.
 The 16-bit type follows the caller like the reference module's does: the reference pipeline calls Stage II inside
 torch.autocast("cuda", dtype=self._dtype) (pipeline.py:679; pipeline_with_3d.py:221), `--dtype float16` from the CLI
 (inference/video_to_animated_mesh.py:153,222) - so a call under autocast(float16) runs the float16 build of the library
@@ -40,7 +46,7 @@ class HipAutoencoder:
     def __init__(self, temporal_context_size: int = 16, in_channels: int = 3, in_extra_channels: int = 3, out_dim: int = 3,
                  latent_channels: int = 64, width: int = 1024, num_layers: int = 16, num_attention_heads: int = 8,
                  embed_frequency: int = 8, embed_include_pi: bool = False, prediction_mode: str = "direct",
-                 verbose: bool = False, dtype=None, **_ignored):
+                 verbose: bool = False, dtype=None, residual_fp32: bool = True, **_ignored):
         if width % num_attention_heads or width // num_attention_heads != ops.HEAD_DIM:
             raise ValueError("HipAutoencoder: the kernels are built for head_dim 128 (width = 128 * heads)")
         if latent_channels % 64 or width % 64:
@@ -54,6 +60,7 @@ class HipAutoencoder:
         self.query_pad = ops.round_up(self.query_dim, 64)
         self.device = torch.device("cpu")
         self.dtype_pinned = None if dtype is None else _L.kind_of(dtype)      # None: the caller's autocast dtype (compute_kind)
+        self.residual_fp32 = bool(residual_fp32)
         self._sd: Optional[Dict[str, torch.Tensor]] = None
         self._w_kind: Dict[str, Dict[str, torch.Tensor]] = {}                 # "bf16" / "f16" -> device weights, uploaded on first use
         lib()      # fail loudly here if libactionmesh_amd.so is missing
@@ -163,6 +170,41 @@ class HipAutoencoder:
         h = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"], residual=qh)
         return self._ff(p, h)
 
+    # the same blocks on an fp32 residual stream (residual_fp32): a branch's linear output is 16-bit, as an autocast linear's is;
+    # `ops.add_layernorm_f32(h32, y, w, b)` adds it into the stream and returns the next FP32LayerNorm's output rounded to 16 bits
+    def _self_stack_f32(self, h32: torch.Tensor, dt16, B: int, T: int, L: int, rope) -> None:
+        w = self._w
+        z = ops.add_layernorm_f32(h32, None, w["blocks.0.norm_s_attn.w"], w["blocks.0.norm_s_attn.b"], dtype=dt16)
+        for i in range(self.num_layers):
+            p = f"blocks.{i}."
+            Q, K, Vt = ops.gemm_head_post(z, w[p + "qkv"], self.heads, (0, 1, 2), T * L, L, rope=rope)
+            a = ops.attention(Q, K, Vt, T * L, T * L)
+            y = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"])
+            z = ops.add_layernorm_f32(h32, y, w[p + "norm_ff.w"], w[p + "norm_ff.b"])
+            f = ops.gemm(z, w[p + "ff1"], bias=w[p + "ff1_b"], gelu=True)
+            y = ops.gemm(f, w[p + "ff2"], bias=w[p + "ff2_b"])
+            if i + 1 < self.num_layers:
+                q = f"blocks.{i + 1}."
+                z = ops.add_layernorm_f32(h32, y, w[q + "norm_s_attn.w"], w[q + "norm_s_attn.b"])
+            else:                       # the kv cache of the cross-attention block: its norm_cross reads the finished stream
+                q = f"blocks.{self.num_layers}."
+                z = ops.add_layernorm_f32(h32, y, w[q + "norm_cross.w"], w[q + "norm_cross.b"])
+        return z                        # norm_cross(kv_cache), 16-bit
+
+    def _cross_block_f32(self, qh32: torch.Tensor, e: torch.Tensor, dt16, B: int, V: int, S: int) -> torch.Tensor:
+        """qh32: the query block's fp32 residual stream (modified in place); e = norm_cross(kv_cache).  Returns norm_out(h), 16-bit."""
+        w, p = self._w, f"blocks.{self.num_layers}."
+        kv = ops.gemm(e, w[p + "kv"])
+        _, K, Vt = ops.head_post(kv, self.heads, (1, 2), S, S)
+        z = ops.add_layernorm_f32(qh32, None, w[p + "norm_x_attn.w"], w[p + "norm_x_attn.b"], dtype=dt16)
+        Q, _, _ = ops.gemm_head_post(z, w[p + "q"], self.heads, (0,), V, V)
+        a = ops.attention(Q, K, Vt, V, S)
+        y = ops.gemm(a, w[p + "o"], bias=w[p + "o_b"])
+        z = ops.add_layernorm_f32(qh32, y, w[p + "norm_ff.w"], w[p + "norm_ff.b"])
+        f = ops.gemm(z, w[p + "ff1"], bias=w[p + "ff1_b"], gelu=True)
+        y = ops.gemm(f, w[p + "ff2"], bias=w[p + "ff2_b"])
+        return ops.add_layernorm_f32(qh32, y, w["norm_out.w"], w["norm_out.b"])
+
     # ---- forward (temporal_autoencoder.py:160-267) --------------------------------------------------------------
     @torch.no_grad()
     def forward(self, latent: torch.Tensor, framestep: torch.Tensor, source_alpha: torch.Tensor,
@@ -196,18 +238,32 @@ class HipAutoencoder:
                                  self.in_extra_channels, self.embed_frequency, self.embed_include_pi, self.query_pad, dtype=dt16)
             qh = ops.gemm(qe, w["proj_query"], bias=w["proj_query_b"])
             out = torch.empty((B, T_out, V, self.out_dim), dtype=torch.float32, device=dev)
+            if self.residual_fp32:
+                base32 = base.float()                                           # am_bf16_to_f32 would do; once per window, torch moves rows
+                alpha32 = torch.cat(emb, -1).to(dev, torch.float32)             # the alpha embedding enters the stream in fp32 (:232-235, :258)
+                qh32_0 = qh.float()
             for i in range(T_out):
                 if step_callback is not None:
                     step_callback(i + 1, T_out)
-                h = base.clone()
-                h.view(B, T, L, C)[:, :, 0] = alpha[:, i][:, None]
-                for li in range(self.num_layers):
-                    h = self._self_block(li, h, B, T, L, rope)
-                hq = self._cross_block(qh, h, B, V, T * L)
-                z = ops.layernorm(hq, w["norm_out.w"], w["norm_out.b"])
+                if self.residual_fp32:
+                    h32 = base32.clone()
+                    h32.view(B, T, L, C)[:, :, 0] = alpha32[:, i][:, None]
+                    e = self._self_stack_f32(h32, dt16, B, T, L, rope)
+                    z = self._cross_block_f32(qh32_0.clone(), e, dt16, B, V, T * L)
+                else:
+                    h = base.clone()
+                    h.view(B, T, L, C)[:, :, 0] = alpha[:, i][:, None]
+                    for li in range(self.num_layers):
+                        h = self._self_block(li, h, B, T, L, rope)
+                    hq = self._cross_block(qh, h, B, V, T * L)
+                    z = ops.layernorm(hq, w["norm_out.w"], w["norm_out.b"])
                 lg = ops.gemm(z, w["proj_out"], bias=w["proj_out_b"])            # (B*V, 8): 3 logits + padding
                 for b in range(B):
                     ops.displacement(lg[b * V:(b + 1) * V], self.out_dim, out[b, i])
+            if dt16 == torch.float16 and not bool(torch.isfinite(out).all()):
+                # IEEE half overflows above 65504 (bfloat16 does not): real checkpoints with outlier activations may need bfloat16
+                raise FloatingPointError("HipAutoencoder: the float16 forward produced non-finite displacements (activation overflow "
+                                         "in IEEE half); run Stage II under autocast(bfloat16) / dtype='bfloat16'")
             return out
 
     __call__ = forward

@@ -524,7 +524,51 @@ __device__ __forceinline__ void store_staged_tile_headpost(const am_gemm_args& p
           *reinterpret_cast<u32x4_t*>(out + (((int64_t)seq * hp.heads + head) * s_pad + sq) * 128 + sub * 8) = w;
         }
       };
-      if (two) {
+      if (two && m0 + B2 <= p.M && wt != nullptr) {
+        // The shape every tile of the main grid has (full tile, qk-norm on): straight-line code, four rows in flight per thread - the
+        // four LDS reads, the four 4-step DPP reductions and the four rsqrt's of a batch overlap instead of queueing behind the
+        // branches of the general form (the epilogue is VALU / latency bound: 8 waves, nothing else on the CU to hide behind).
+        // Same operations in the same order on every element as one_row(): bit-identical.  v_rsq_f32 without rsqrtf's denormal
+        // rescue: its argument is >= eps (1e-6 > FLT_MIN), the rescue branch is never taken, the result is the same instruction's.
+        const bool rope = hp.rope_cos != nullptr;
+#pragma unroll 1
+        for (int b4 = 0; b4 < 16; b4 += 4) {
+          u32x4_t u[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const u32x4_t*>(su + (b4 + i) * 8192);
+          float v[4][8], ss[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (odd) u[i] = u32x4_t{u[i][2], u[i][3], u[i][0], u[i][1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][2 * e] = bflo(u[i][e]); v[i][2 * e + 1] = bfhi(u[i][e]); }
+            ss[i] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss[i] = __builtin_fmaf(v[i][e], v[i][e], ss[i]);
+          }
+#define AM_HP_DPP(CTRL)                                                                                                         \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                         \
+            ss[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss[i]), CTRL, 0xf, 0xf, false));
+          AM_HP_DPP(0x128) AM_HP_DPP(0x124) AM_HP_DPP(0x122) AM_HP_DPP(0x121)
+#undef AM_HP_DPP
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + (b4 + i) * 16 + r16;
+            const float r = __builtin_amdgcn_rsqf(ss[i] * (1.0f / 128.0f) + hp.eps);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] * r) * wv[e];
+            if (rope) {
+              const bool nx = gm >= fb;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rope_rotate(v[i][2 * e], v[i][2 * e + 1], nx ? cs1[e] : cs0[e], nx ? sn1[e] : sn0[e]);
+            }
+            u32x4_t w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pack_bf2(v[i][2 * e], v[i][2 * e + 1]);
+            *reinterpret_cast<u32x4_t*>((gm >= sb ? out1 : out0) + (int64_t)gm * 128) = w;
+          }
+        }
+      } else if (two) {
 #pragma unroll 4
         for (int pass = 0; pass < 16; ++pass) one_row(pass);
       } else {

@@ -393,6 +393,84 @@ __global__ __launch_bounds__(256) void head_post_kernel(am_headpost_args p, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp32 residual stream (round 6).  The reference's Stage II keeps its residual stream in fp32: torch.cat of the bf16 projected
+// latents with the fp32 alpha embedding promotes (temporal_autoencoder.py:258), every `h + branch` under autocast then adds a 16-bit
+// linear output into fp32, FP32LayerNorm returns fp32 and the next autocast linear rounds its input to 16 bits; the DINOv2 encoder runs
+// in fp32 altogether (pipeline.py:665-667).  One pass per branch:  h32 += y16 (the branch's 16-bit linear output; may be NULL), then
+// z16 = LayerNorm(h32) rounded to 16 bits for the next linear (z16 / w / b may be NULL: accumulate only).  One wave per row.
+template <int NCH>
+__global__ __launch_bounds__(256) void add_layernorm_f32_kernel(float* __restrict__ h, const bf16_t* __restrict__ y, bf16_t* __restrict__ z,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* hr = h + row * C;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (j * 64 + lane) * 8;
+    if (col < C) {
+      const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(hr + col), h1 = *reinterpret_cast<const f32x4_t*>(hr + col + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[j][e] = h0[e]; v[j][4 + e] = h1[e]; }
+      if (y) {
+        const u32x4_t u = *reinterpret_cast<const u32x4_t*>(y + row * C + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][2 * e] += bflo(u[e]); v[j][2 * e + 1] += bfhi(u[e]); }
+        *reinterpret_cast<f32x4_t*>(hr + col) = f32x4_t{v[j][0], v[j][1], v[j][2], v[j][3]};
+        *reinterpret_cast<f32x4_t*>(hr + col + 4) = f32x4_t{v[j][4], v[j][5], v[j][6], v[j][7]};
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[j][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    }
+  }
+  if (z == nullptr) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (j * 64 + lane) * 8;
+    if (col < C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[j][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  bf16_t* zr = z + row * C;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int col = (j * 64 + lane) * 8;
+    if (col < C) {
+      const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(w + col), w1 = *reinterpret_cast<const f32x4_t*>(w + col + 4);
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(b + col), b1 = *reinterpret_cast<const f32x4_t*>(b + col + 4);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (v[j][e] - mean) * rstd * w0[e] + b0[e];
+        o[4 + e] = (v[j][4 + e] - mean) * rstd * w1[e] + b1[e];
+      }
+      u32x4_t u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = pack_bf2(o[2 * e], o[2 * e + 1]);
+      *reinterpret_cast<u32x4_t*>(zr + col) = u;
+    }
+  }
+}
+
 int launch_layernorm(const uint16_t* x, uint16_t* y, const float* w, const float* b, int64_t rows, int C, float eps, float* stats,
                      void* stream) {
   const dim3 grid(ceil_div(rows, 4)), block(256);
@@ -414,6 +492,26 @@ extern "C" int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w,
   AM_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, "am_layernorm_bf16: bad shape rows=%lld C=%d", (long long)rows, C);
   AM_CHECK(((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) % 16 == 0, "am_layernorm_bf16: operands misaligned");
   return launch_layernorm(x, y, w, b, rows, C, eps, nullptr, stream);
+}
+
+extern "C" int am_add_layernorm_f32(float* h, const uint16_t* y, uint16_t* z, const float* w, const float* b, int64_t rows, int C, float eps,
+                                    void* stream) {
+  AM_CHECK(h, "am_add_layernorm_f32: null residual stream");
+  AM_CHECK(z == nullptr || (w && b), "am_add_layernorm_f32: a LayerNorm output needs weight and bias");
+  AM_CHECK(y || z, "am_add_layernorm_f32: nothing to do (neither a branch to add nor an output)");
+  AM_CHECK(rows > 0 && C > 0 && C % 8 == 0 && C <= 4096, "am_add_layernorm_f32: bad shape rows=%lld C=%d", (long long)rows, C);
+  AM_CHECK(((uintptr_t)h | (uintptr_t)y | (uintptr_t)z | (uintptr_t)w | (uintptr_t)b) % 16 == 0, "am_add_layernorm_f32: operands misaligned");
+  const dim3 grid(ceil_div(rows, 4)), block(256);
+  const int nch = ceil_div(C, 512);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* yy = reinterpret_cast<const bf16_t*>(y);
+  bf16_t* zz = reinterpret_cast<bf16_t*>(z);
+  if (nch <= 1) hipLaunchKernelGGL(add_layernorm_f32_kernel<1>, grid, block, 0, s, h, yy, zz, w, b, rows, C, eps);
+  else if (nch <= 2) hipLaunchKernelGGL(add_layernorm_f32_kernel<2>, grid, block, 0, s, h, yy, zz, w, b, rows, C, eps);
+  else if (nch <= 4) hipLaunchKernelGGL(add_layernorm_f32_kernel<4>, grid, block, 0, s, h, yy, zz, w, b, rows, C, eps);
+  else hipLaunchKernelGGL(add_layernorm_f32_kernel<8>, grid, block, 0, s, h, yy, zz, w, b, rows, C, eps);
+  AM_HIP(hipGetLastError());
+  return AM_OK;
 }
 
 extern "C" int am_layernorm_stats_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,

@@ -19,8 +19,11 @@ How the ViT maps onto kernels that were built for head_dim 128:
     GEMM operands of a component that runs once per video (~0.4 % of one 50-step window) - not worth a second kernel;
   * LayerScale is folded into the out-projection / fc2 weights and biases at load time; the residual add is the GEMM
     epilogue's.
-Precision: bf16 storage / fp32 accumulation (the reference runs this model in fp32); tolerance stated in
-tests/test_image_encoder.py.
+Precision: 16-bit MFMA operands / fp32 accumulation, and - round 6, `residual_fp32=True`, the default - an **fp32 residual stream**:
+the reference runs this model in fp32, outside its autocast region (pipeline.py:665-667), so what the 16-bit path loses is the rounding
+of the GEMM operands / outputs, not 24 layers of re-rounding the stream (`am_add_layernorm_f32` adds each branch's 16-bit output into
+the fp32 stream and emits the next LayerNorm's 16-bit output; `residual_fp32=False` is the round-5 all-16-bit stream).  Tolerances
+stated in tests/test_image_encoder.py.
 """
 from __future__ import annotations
 
@@ -104,8 +107,10 @@ def position_rows(pos: torch.Tensor, cls: torch.Tensor, trained_side: int, n_h: 
 
 class HipImageEncoder:
     def __init__(self, pretrained_dino_feature_extractor: Optional[str] = None, pretrained_dino_model: Optional[str] = None,
-                 config: Optional[Dict] = None, state_dict: Optional[Dict[str, torch.Tensor]] = None, dtype=None, **_ignored):
+                 config: Optional[Dict] = None, state_dict: Optional[Dict[str, torch.Tensor]] = None, dtype=None,
+                 residual_fp32: bool = True, **_ignored):
         lib()      # fail loudly here if libactionmesh_amd.so is missing
+        self.residual_fp32 = bool(residual_fp32)
         # 16-bit storage type.  The reference encodes OUTSIDE its autocast region, in fp32 (pipeline.py:665-667): there is no caller dtype
         # to follow, so the default is bfloat16 (fp32's exponent range: safe for DINOv2's outlier tokens whatever the checkpoint) and
         # dtype="float16" selects the float16 build - 8x finer rounding, measured closer to the fp32 reference on the ViT-L/14 fixture
@@ -192,6 +197,15 @@ class HipImageEncoder:
             self._pos_cache = {key: rows.to(self._device, self.dt16)[None].expand(T, -1, -1).reshape(T * rows.shape[0], -1).contiguous()}
         return self._pos_cache[key]
 
+    def _pos_rows32(self, T: int, n_h: int, n_w: int) -> torch.Tensor:
+        """The same rows in fp32 (the fp32 residual stream starts from them)."""
+        key = (T, n_h, n_w, 32)
+        if key not in self._pos_cache:
+            side = self.cfg["image_size"] // self.cfg["patch_size"]
+            rows = position_rows(self._packed["pos"], self._packed["cls"], side, n_h, n_w)
+            self._pos_cache[key] = rows.to(self._device, torch.float32)[None].expand(T, -1, -1).reshape(T * rows.shape[0], -1).contiguous()
+        return self._pos_cache[key]
+
     # ---- forward ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def encode_pixels(self, pixel_values: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
@@ -210,16 +224,39 @@ class HipImageEncoder:
             pix = pixel_values.to(dev, torch.float32).contiguous()
             pos = self._pos_rows(T, n_h, n_w)
             dt16 = self.dt16
-            h = torch.empty((T * S, C), dtype=dt16, device=dev)
-            ops.gemm(ops.patchify(pix, p, w["patch.w"].shape[1], dtype=dt16), w["patch.w"], bias=w["patch.b"], residual=pos, out=h,
-                     c_map=(npatch, S, 1), M=T * npatch)
-            h.view(T, S, C)[:, 0] = pos[0]                                        # class token + its position
             HP = ops.HEAD_DIM
             Q = torch.zeros((T, H, ops.round_up(S, 256), HP), dtype=dt16, device=dev)
             K = torch.zeros((T, H, ops.round_up(S, 64), HP), dtype=dt16, device=dev)
             Vt = torch.zeros((T, H, HP, ops.round_up(S, 64)), dtype=dt16, device=dev)
             scale = float(C // H) ** -0.5
-            for i in range(cfg["num_hidden_layers"]):
+            NL = cfg["num_hidden_layers"]
+            if self.residual_fp32:
+                # fp32 stream: starts as the fp32 position rows (class token + its position in row 0 of every frame); the patch
+                # embedding's 16-bit output is the first branch added into it (its class-token rows are zero)
+                h32 = self._pos_rows32(T, n_h, n_w).clone()
+                y = torch.zeros((T * S, C), dtype=dt16, device=dev)
+                ops.gemm(ops.patchify(pix, p, w["patch.w"].shape[1], dtype=dt16), w["patch.w"], bias=w["patch.b"], out=y,
+                         c_map=(npatch, S, 1), M=T * npatch)
+                for i in range(NL):
+                    q = f"l{i}."
+                    z = ops.add_layernorm_f32(h32, y, w[q + "norm1.w"], w[q + "norm1.b"], eps=eps)
+                    qkv = ops.gemm(z, w[q + "qkv.w"], bias=w[q + "qkv.b"])
+                    ops.head_post(qkv, H, (0, 1, 2), S, S, out_q=Q, out_k=K, out_vt=Vt)
+                    a = ops.attention(Q, K, Vt, S, S, scale=scale)
+                    y = ops.gemm(a, w[q + "o.w"], bias=w[q + "o.b"])
+                    z = ops.add_layernorm_f32(h32, y, w[q + "norm2.w"], w[q + "norm2.b"], eps=eps)
+                    f = ops.gemm(z, w[q + "fc1.w"], bias=w[q + "fc1.b"], gelu=True)
+                    y = ops.gemm(f, w[q + "fc2.w"], bias=w[q + "fc2.b"])
+                out = ops.add_layernorm_f32(h32, y, w["norm.w"], w["norm.b"], eps=eps).view(T, S, C)
+                if dt16 == torch.float16 and not bool(torch.isfinite(out).all()):
+                    raise FloatingPointError("HipImageEncoder: the float16 forward produced non-finite features (IEEE half overflows above "
+                                             "65504: DINOv2 outlier tokens); use dtype='bfloat16'")
+                return out if out_dtype == out.dtype else out.to(out_dtype)
+            h = torch.empty((T * S, C), dtype=dt16, device=dev)
+            ops.gemm(ops.patchify(pix, p, w["patch.w"].shape[1], dtype=dt16), w["patch.w"], bias=w["patch.b"], residual=pos, out=h,
+                     c_map=(npatch, S, 1), M=T * npatch)
+            h.view(T, S, C)[:, 0] = pos[0]                                        # class token + its position
+            for i in range(NL):
                 q = f"l{i}."
                 z = ops.layernorm(h, w[q + "norm1.w"], w[q + "norm1.b"], eps=eps)
                 qkv = ops.gemm(z, w[q + "qkv.w"], bias=w[q + "qkv.b"])

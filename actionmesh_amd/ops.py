@@ -172,6 +172,32 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e
     return out
 
 
+def add_layernorm_f32(h32: torch.Tensor, y: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None,
+                      b: Optional[torch.Tensor] = None, eps: float = 1e-5, out: Optional[torch.Tensor] = None,
+                      dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
+    """am_add_layernorm_f32 - the fp32 residual stream of the reference's Stage II / DINOv2 encoder in one pass:
+    h32 (rows, C) fp32 += y (rows, C) 16-bit (None: nothing to add), IN PLACE; returns LayerNorm(h32) * w + b rounded to the 16-bit type
+    (`dtype`, or y's) for the next linear - or None when w is None (accumulate only)."""
+    _need(h32, torch.float32, "h32")
+    Cdim = h32.shape[-1]
+    rows = h32.numel() // Cdim
+    if y is not None:
+        _need(y, H16, "y")
+        assert y.numel() == h32.numel()
+        dtype = y.dtype
+    if w is None:
+        assert y is not None, "add_layernorm_f32: nothing to do"
+        _launch(h32, _fn(dtype, "am_add_layernorm_f32"), "am_add_layernorm_f32", h32.data_ptr(), y.data_ptr(), None, None, None, rows, Cdim, eps)
+        return None
+    assert dtype in H16, "add_layernorm_f32: the 16-bit output type must be given when there is no branch to take it from"
+    _need(w, torch.float32, "w"); _need(b, torch.float32, "b")
+    if out is None:
+        out = torch.empty(h32.shape, dtype=dtype, device=h32.device)
+    _launch(h32, _fn(dtype, "am_add_layernorm_f32"), "am_add_layernorm_f32", h32.data_ptr(), _p(y), _need(out, dtype, "out").data_ptr(),
+            w.data_ptr(), b.data_ptr(), rows, Cdim, eps)
+    return out
+
+
 def head_post(x: torch.Tensor, heads: int, kinds: Sequence[int], seq_len: int, rows_per_frame: int,
               w_q: Optional[torch.Tensor] = None, w_k: Optional[torch.Tensor] = None,
               rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, eps: float = 1e-6,

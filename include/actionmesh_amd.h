@@ -223,6 +223,14 @@ int am_ln_fold_weight(const uint16_t* W, const float* gamma, const float* beta, 
 int am_layernorm_bf16(const uint16_t* x, uint16_t* y, const float* w, const float* b,
                       int64_t rows, int C, float eps, void* stream);
 
+/* fp32 residual stream (Stage II, temporal_autoencoder.py:258: the reference's torch.cat promotes its residual stream to fp32, every
+ * `h + branch` under autocast adds a 16-bit linear output into it, FP32LayerNorm reads it in fp32 and the next autocast linear rounds its
+ * input to 16 bits; the DINOv2 encoder, image_encoder.py:38-55 / pipeline.py:665-667, runs in fp32).  One pass:
+ *   h32 [rows][C] += y16 [rows][C]   (the branch's 16-bit output; NULL: nothing to add),
+ *   z16 [rows][C]  = LayerNorm(h32) * w + b, rounded to 16 bits   (NULL: accumulate only).   C % 8 == 0, C <= 4096. */
+int am_add_layernorm_f32(float* h32, const uint16_t* y16, uint16_t* z16, const float* w, const float* b, int64_t rows, int C, float eps,
+                         void* stream);
+
 /* Head split + qk RMSNorm + RoPE + attention operand layout
  * (attention_processor.py:106-130).
  *   X [rows][ldx] bf16; head h, part p at columns (h*nparts + p)*128.

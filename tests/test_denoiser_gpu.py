@@ -550,7 +550,9 @@ def test_folded_layernorms(dev, golden_dir, name, monkeypatch):
     """norm_s_attn / norm_x_attn / norm_ff live inside the linears behind them (am_model.hip).  (1) The row statistics a
     producer GEMM leaves behind are the same BITS as a read-back of the rows (ACTIONMESH_AMD_LN_STATS=recompute) on a whole
     forward; (2) the round-3 sequence - LayerNorm kernel, bf16 activation, plain linear: ACTIONMESH_AMD_LN_FOLD=0 - differs only
-    by the rounding of that activation, and is no closer to the reference than the folded form."""
+    by the rounding of that activation, and is no closer to the reference than the folded form.  Round 6: norm_out is folded into
+    proj_out as well (temporal_denoiser.py:239-242), so the two sequences now differ in one more rounding per row - the stated distance
+    between them goes from 8e-3 to 9e-3 (measured 8.1e-3 on tiny_inflated; both are 8.4-8.5e-3 from the reference's fp32)."""
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser
     g, cfg, sd, model, t = _setup(name, golden_dir, dev)
     cfgd = ClassifierFreeGuidance(True, [[0, 1], [1, 1]], [7.5])
@@ -573,7 +575,7 @@ def test_folded_layernorms(dev, golden_dir, name, monkeypatch):
     v0 = run({"ACTIONMESH_AMD_LN_FOLD": "0"})
     ref32 = torch.from_numpy(g["fwd_velocity_fp32"])
     print(f"{name}: folded vs un-folded rel-L2 {rel(v, v0):.3e}; vs reference fp32: folded {rel(v, ref32):.3e}, un-folded {rel(v0, ref32):.3e}")
-    assert rel(v, v0) < 8e-3
+    assert rel(v, v0) < 9e-3
     assert rel(v, ref32) < 1.05 * rel(v0, ref32)
 
 

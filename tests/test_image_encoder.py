@@ -178,25 +178,28 @@ def test_oracle_matches_transformers_at_vitl():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("residual_fp32", [True, False])
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-def test_hip_encoder_vitl_against_transformers(dtype):
+def test_hip_encoder_vitl_against_transformers(dtype, residual_fp32):
     """The HIP encoder at ViT-L/14, all 24 layers, against transformers.Dinov2Model's own fp32 last_hidden_state.  The reference
-    encodes in fp32 (outside its autocast region, pipeline.py:665-667), so a 16-bit encoder is NARROWER than the reference's
-    arithmetic; stated: bfloat16 rel-L2 <= 2 x transformers' own autocast(bf16) distance (5.8e-3, in the fixture) + 2e-3, max abs <=
-    0.15 on unit-variance outputs - the factor 2 (measured 1.15e-2 on MI355X, round 5) is the bf16 RESIDUAL STREAM: torch's autocast keeps
-    the residual in fp32 and rounds only the linears' operands and outputs, this path stores every activation of the 24 layers in the
-    16-bit type; float16 (`HipImageEncoder(dtype="float16")`, measured 1.4e-3) rel-L2 <= 2e-3.  Measured values are printed."""
+    encodes in fp32 (outside its autocast region, pipeline.py:665-667), so a 16-bit encoder is NARROWER than the reference's arithmetic.
+    Round 6 (VERDICT r05 next #4b): the residual stream is fp32 by default (`residual_fp32=True`), which is what torch's own autocast
+    keeps in fp32 as well - so the bfloat16 statement becomes transformers' OWN autocast(bf16) distance (5.8e-3, in the fixture):
+      residual_fp32=True:  bfloat16 rel-L2 <= 1.25 x ref_autocast + 2e-3, max abs <= 0.1;  float16 <= 1.5e-3, max abs <= 1.5e-2;
+      residual_fp32=False (the round-5 all-16-bit stream): bfloat16 <= 2 x ref_autocast + 2e-3 (measured 1.15e-2), float16 <= 2e-3 (1.4e-3).
+    Measured values are printed."""
     g, cfg, sd, pixels, ref, stride = _vitl_case()
-    enc = IE.HipImageEncoder(state_dict=sd, dtype=dtype).to("cuda:0")
+    enc = IE.HipImageEncoder(state_dict=sd, dtype=dtype, residual_fp32=residual_fp32).to("cuda:0")
     out = enc.encode_pixels(pixels.cuda()).cpu()
     assert out.shape == (2, 257, 1024) and out.dtype == torch.float32 and bool(torch.isfinite(out).all())
     r, mx = _rel(out[:, ::stride], ref), float((out[:, ::stride] - ref).abs().max())
     ref16 = float(g["ref_autocast_bf16_rel"])
-    print(f"HIP DINOv2 ViT-L/14 24 layers, {dtype}: rel-L2 vs transformers fp32 {r:.3e} (transformers' own autocast(bf16): {ref16:.3e}), max abs {mx:.3e}")
+    print(f"HIP DINOv2 ViT-L/14 24 layers, {dtype}, residual stream {'fp32' if residual_fp32 else '16-bit'}: rel-L2 vs transformers fp32 {r:.3e} "
+          f"(transformers' own autocast(bf16): {ref16:.3e}), max abs {mx:.3e}")
     if dtype == "bfloat16":
-        assert r <= 2.0 * ref16 + 2e-3 and mx <= 0.15, (r, mx)
+        assert (r <= 1.25 * ref16 + 2e-3 and mx <= 0.1) if residual_fp32 else (r <= 2.0 * ref16 + 2e-3 and mx <= 0.15), (r, mx)
     else:
-        assert r <= 2e-3 and mx <= 2e-2, (r, mx)
+        assert (r <= 1.5e-3 and mx <= 1.5e-2) if residual_fp32 else (r <= 2e-3 and mx <= 2e-2), (r, mx)
 
 
 @pytest.mark.gpu

@@ -652,3 +652,29 @@ def test_f32_to_bf16(dev):
     x = _randn((1000003,), 1, dev) * 100
     assert torch.equal(ops.f32_to_bf16(x), x.to(torch.bfloat16))
 
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C", [1024, 320, 2048])
+def test_add_layernorm_f32(dtype, C):
+    """am_add_layernorm_f32 (round 6: the fp32 residual stream of the reference's Stage II / DINOv2 encoder, temporal_autoencoder.py:258):
+    h32 += y16 in place, z16 = LayerNorm(h32) rounded to 16 bits - against torch in fp32; the accumulate-only and LayerNorm-only forms."""
+    from actionmesh_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(C)
+    rows = 777
+    h = torch.randn((rows, C), device=dev, generator=g) * 3 + 2
+    y = torch.randn((rows, C), device=dev, generator=g).to(dtype)
+    w = torch.rand(C, device=dev, generator=g) + 0.5
+    b = torch.randn(C, device=dev, generator=g) * 0.3
+    h_ref = h + y.float()
+    z_ref = torch.nn.functional.layer_norm(h_ref, (C,), w, b, 1e-5)
+    h1 = h.clone()
+    z = ops.add_layernorm_f32(h1, y, w, b)
+    assert torch.equal(h1, h_ref)                                                   # one fp32 add per element: exact
+    assert z.dtype == dtype and float((z.float() - z_ref).abs().max()) <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * float(z_ref.abs().max())
+    assert float((z.float() - z_ref).norm() / z_ref.norm()) < (2.5e-3 if dtype == torch.bfloat16 else 3.5e-4)
+    h2 = h.clone()
+    assert ops.add_layernorm_f32(h2, y) is None and torch.equal(h2, h_ref)          # accumulate only
+    z3 = ops.add_layernorm_f32(h_ref.clone(), None, w, b, dtype=dtype)              # LayerNorm only: the same bits
+    assert torch.equal(z3, z)

@@ -34,7 +34,7 @@ def main():
             sd[name] = 0.5 * torch.randn(shape, generator=g)
         else:
             sd[name] = torch.zeros(shape)
-    enc = IE.HipImageEncoder(state_dict=sd, dtype=a.dtype).to(dev)
+    enc = IE.HipImageEncoder(state_dict=sd, dtype=a.dtype, residual_fp32=os.environ.get("ACTIONMESH_AMD_RESIDUAL_FP32", "1") != "0").to(dev)
     pix = torch.randn((a.frames, 3, 224, 224), generator=g).to(dev)
     out = enc.encode_pixels(pix)
     torch.cuda.synchronize()

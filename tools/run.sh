@@ -141,5 +141,21 @@ print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['
 import json; d=json.load(open('gpurun_out/r06b_bench.json')); r=d['roofline']
 print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'], d['latents_fingerprint'])"
     ;;
+  r06c)   # fp32 residual streams (Stage II, DINOv2), the batched QK epilogue, norm_out fold: tests + timings
+    PT="python -m pytest -q -m gpu --timeout=600 --durations=8 -rA"
+    timeout 1800 $PT tests/test_kernels_gpu.py tests/test_ln_fold_gpu.py tests/test_denoiser_gpu.py tests/test_f16_gpu.py tests/test_autoencoder.py tests/test_image_encoder.py \
+      2>&1 | grep -v "^$" | grep -E "passed|failed|FAILED|ERROR|Stage II at|HIP DINOv2|rel-L2|Error" | cut -c1-330 | tee gpurun_out/r06c_tests.txt
+    python tools/kernel_bench.py --shape headline --only fused --reps 20 2>&1 | grep -E "qkv|cross" | tee gpurun_out/r06c_fused_headline.txt
+    for dt in bfloat16 float16; do
+      for rf in 1 0; do
+        ACTIONMESH_AMD_RESIDUAL_FP32=$rf python tools/stage2_bench.py --dtype $dt 2>/dev/null | tail -1 | tee gpurun_out/r06c_stage2_${dt}_res$rf.json | cut -c1-330
+        ACTIONMESH_AMD_RESIDUAL_FP32=$rf python tools/encoder_bench.py --dtype $dt 2>/dev/null | tail -1 | tee gpurun_out/r06c_encoder_${dt}_res$rf.json | cut -c1-330
+      done
+    done
+    timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r06c_bench.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r06c_bench.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'], d['latents_fingerprint'])"
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

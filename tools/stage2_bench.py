@@ -36,7 +36,8 @@ def main():
             sd[name] = torch.ones(shape)
         else:
             sd[name] = torch.zeros(shape)
-    m = HipAutoencoder(width=C, num_layers=a.layers, num_attention_heads=H, dtype=a.dtype)
+    m = HipAutoencoder(width=C, num_layers=a.layers, num_attention_heads=H, dtype=a.dtype,
+                       residual_fp32=os.environ.get("ACTIONMESH_AMD_RESIDUAL_FP32", "1") != "0")   # A/B of the round-6 fp32 residual stream
     m.load_state_dict(sd)
     m.to(dev)
     T, N, V, To = a.frames, a.tokens, a.vertices, a.targets

@@ -379,23 +379,25 @@ def test_autoregressive_windows_configs2_at_the_headline_architecture(dev, golde
     """BASELINE configs[2]: 32 frames, window 16, slide 15, anchor frame 0 - the THREE sequentially
     dependent windows [0..15], [15..30], [16..31] of the reference (timesteps.py:77-117) - through the device-resident
     LatentBank at the HEADLINE architecture (21 layers, depth-10 skips, width 1024, 8 heads, Dc 1024, S 257) at a reduced token count
-    (47 latent tokens per frame -> 768-token inflated sequences) and 3 sampler steps per window, against the CPU oracle's restatement of
-    pipeline.py:247-314 / 469-506 (oracle/windows_oracle.py, fp32, recomputed here) with the same CPU-drawn noise.  Window 2 conditions on
-    window 1's frame 15, window 3 on window 2's frames 16..30.
-    Stated tolerance, frame by frame: rel-L2 vs the fp32 oracle <= 1.15 x (what reduced precision ITSELF costs on this case) + 2e-3, the
-    yardstick being the oracle's bf16-policy run against its fp32 run (tests/golden/ar_configs2_yardstick.json, oracle/
-    make_golden_ar_configs2.py): 2.7e-2 .. 3.0e-2 per frame - with only 3 coarse steps per window (dt ~ 0.33) twice the 30-step figure.
-    MEASURED on MI355X (round 5): 2.91e-2 / 2.94e-2 / 2.94e-2 (window 1 max, frames 16..30 max, frame 31): the HIP path sits ON the
-    reduced-precision distance and does not grow through the two generations of conditioning frames."""
-    import json
+    (47 latent tokens per frame -> 768-token inflated sequences) and 3 sampler steps per window, with the same CPU-drawn noise.
+    Window 2 conditions on window 1's frame 15, window 3 on window 2's frames 16..30.
+    Round 6 (VERDICT r05 next #4c): BOTH halves of the statement now come from the REFERENCE's own modules (tests/golden/ar_configs2_ref.npz,
+    oracle/make_golden_ar_configs2_ref.py: the reference's chunk_from, LatentBank, SchedulerFlow, ClassifierFreeGuidance and ActionMeshDenoiser
+    under the window loop of pipeline.py:247-314 / 469-506): the fp32 latents of all 32 frames, and the reference's OWN reduced-precision
+    distance per frame (the same loop under autocast("cpu", bfloat16) vs its fp32 run: 2.72e-2 .. 2.98e-2 - with only 3 coarse steps per
+    window, dt ~ 0.33, twice the 30-step figure).  Round 5 used the oracle's fp32 run and the oracle's bf16-policy distance instead; the
+    two agree (same fp32 checksum to the last bit, yardsticks within 4 %: tests/test_oracle_golden.py).
+    Stated tolerance, frame by frame: rel-L2 vs the reference's fp32 latents <= 1.15 x (the reference's own autocast distance) + 2e-3.
+    MEASURED on MI355X (round 5, against the oracle's figures): 2.91e-2 / 2.94e-2 / 2.94e-2 (window 1 max, frames 16..30 max, frame 31)."""
+    import numpy as np
     from actionmesh_amd import ClassifierFreeGuidance, HipDenoiser, HipSchedulerFlow
     from actionmesh_amd import windows as W
     from oracle import denoiser_oracle as O
-    from oracle import windows_oracle as WO
     from oracle.make_golden_ar_configs2 import HP as hp, N, D, S, STEPS as steps, T, case
-    yard = json.load(open(os.path.join(golden_dir, "ar_configs2_yardstick.json")))
+    fx = np.load(os.path.join(golden_dir, "ar_configs2_ref.npz"))
     cfg, sd, ts, context, anchor = case()
-    assert O.state_dict_checksum(sd) == pytest.approx(yard["weights_checksum"], rel=1e-12) and (yard["frames"], yard["tokens"], yard["steps"]) == (T, N, steps)
+    assert O.state_dict_checksum(sd) == pytest.approx(float(fx["weights_checksum"]), rel=1e-12)
+    assert (int(fx["frames"]), int(fx["tokens"]), int(fx["steps"])) == (T, N, steps)
     model = HipDenoiser(num_tokens_nominal=N, temporal_context_size=16, **hp)
     model.load_state_dict(sd)
     model.to(dev).eval()
@@ -406,23 +408,17 @@ def test_autoregressive_windows_configs2_at_the_headline_architecture(dev, golde
     bank = W.LatentBank(empty_dims=(N, D), device=str(dev))
     bank.update(ts[0:1], anchor)
     W.generate_3d_latents(model, sched, cfgd, ts, context.to(dev), bank, anchor_idx=0, window=16, slide=15,
-                          latent_shape=(N, D), seed=44, device=dev, noise_device="cpu")
-    from conftest import host_threads
-    host_threads()
-    ref = WO.ListLatentBank((N, D))
-    ref.update(ts[0:1], anchor)
-    WO.generate_3d_latents(sd, cfg, ts, context, ref, 0, 16, 15, (N, D), steps, seed=44)
+                          latent_shape=(N, D), seed=int(fx["seed"]), device=dev, noise_device="cpu")
     torch.cuda.synchronize()
     lat, t_sorted = bank.get_ordered()
-    lat_ref, t_ref = ref.get_ordered()
-    assert float(lat_ref.double().sum()) == pytest.approx(yard["fp32_checksum"], abs=0.5), "the fp32 oracle run the yardstick was taken against"
-    assert t_sorted.cpu().tolist() == t_ref.tolist() == list(range(T))
-    assert torch.equal(lat[0].cpu(), anchor[0]), "the anchor latent is conditioning only"
+    lat_ref = torch.from_numpy(fx["latents_fp32"])
+    assert t_sorted.cpu().tolist() == list(range(T))
+    assert torch.equal(lat[0].cpu(), anchor[0]) and torch.equal(lat_ref[0], anchor[0]), "the anchor latent is conditioning only"
     per_frame = [rel(lat[i].cpu(), lat_ref[i]) for i in range(1, T)]
-    yd = yard["bf16_policy_vs_fp32_per_frame"][1:]
-    print("configs[2] AR windows at the headline architecture: per-frame rel-L2 vs the fp32 oracle: window 1 max "
+    yd = fx["ref_autocast_bf16_vs_fp32_per_frame"][1:].tolist()
+    print("configs[2] AR windows at the headline architecture: per-frame rel-L2 vs the REFERENCE's fp32 latents: window 1 max "
           f"{max(per_frame[:15]):.2e}, frames 16..30 max {max(per_frame[15:30]):.2e}, frame 31 {per_frame[30]:.2e}; "
-          f"reduced-precision yardstick max {max(yd):.2e}; worst ratio {max(p / y for p, y in zip(per_frame, yd)):.3f}")
+          f"the reference's own autocast(bf16) distance max {max(yd):.2e}; worst ratio {max(p / y for p, y in zip(per_frame, yd)):.3f}")
     for i, (p_, y_) in enumerate(zip(per_frame, yd)):
         assert p_ <= 1.15 * y_ + 2e-3, (i + 1, p_, y_)
 

@@ -168,3 +168,29 @@ def test_forward_rows_is_the_full_forward_on_those_rows(inflated):
     vr = O.denoiser_forward_rows(sd, cfg, x, ctx, fs, t, mask, rows, frame_chunk=2)
     ref = torch.stack([v[b, f, n] for b, f, n in rows.tolist()])
     assert float((vr - ref).abs().max()) < 1e-5
+
+
+def test_window_loop_oracle_reproduces_the_reference_configs2_run(golden_dir):
+    """BASELINE configs[2] (32 frames -> three dependent windows) at the headline architecture: the oracle's restatement of the window
+    loop (oracle/windows_oracle.py over oracle/denoiser_oracle.py, fp32) against the latents the REFERENCE's own modules produced for the
+    same case (tests/golden/ar_configs2_ref.npz, oracle/make_golden_ar_configs2_ref.py) - fp32 vs fp32, so the statement is tight: every
+    frame within 2e-5 rel-L2 (different summation orders of two fp32 implementations through 3 windows x 3 steps x 21 layers).  The
+    round-5 yardstick (the oracle's bf16 POLICY vs its fp32, ar_configs2_yardstick.json) stays within 5 % of the reference's own
+    autocast(bf16) distance frame by frame: the restated rounding points cost what the reference's autocast costs."""
+    import json
+    from oracle import windows_oracle as WO
+    from oracle.make_golden_ar_configs2 import N, D, STEPS, T, case
+    fx = np.load(os.path.join(golden_dir, "ar_configs2_ref.npz"))
+    cfg, sd, ts, context, anchor = case()
+    assert O.state_dict_checksum(sd) == pytest.approx(float(fx["weights_checksum"]), rel=1e-12)
+    bank = WO.ListLatentBank((N, D))
+    bank.update(ts[0:1], anchor)
+    WO.generate_3d_latents(sd, cfg, ts, context, bank, 0, 16, 15, (N, D), STEPS, seed=int(fx["seed"]))
+    lat, t_sorted = bank.get_ordered()
+    ref = torch.from_numpy(fx["latents_fp32"])
+    assert t_sorted.tolist() == list(range(T)) and torch.equal(lat[0], ref[0])
+    worst = max(float((lat[i].double() - ref[i].double()).norm() / ref[i].double().norm()) for i in range(1, T))
+    assert worst < 2e-5, worst
+    yard = json.load(open(os.path.join(golden_dir, "ar_configs2_yardstick.json")))["bf16_policy_vs_fp32_per_frame"][1:]
+    own = fx["ref_autocast_bf16_vs_fp32_per_frame"][1:].tolist()
+    assert all(0.95 <= a / b <= 1.05 for a, b in zip(yard, own)), (min(a / b for a, b in zip(yard, own)), max(a / b for a, b in zip(yard, own)))

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--skew-gemm", action="store_true", help="gemm: time the per-XCD start-skew experiment (act bits 13-15)")
     ap.add_argument("--ablate-gemm", action="store_true", help="gemm: time the epilogue ablations (no C stores / no residual loads)")
     ap.add_argument("--product-only", action="store_true", help="attention: the product launch only (PMC passes)")
+    ap.add_argument("--gemm-names", default="", help="gemm: only the named layer shapes (comma list of qkv, attn-out+res, ff1+gelu, ff2+res, skip(2C)): "
+                    "one shape per counter pass, so that a PMC record belongs to ONE launch shape")
     ap.add_argument("--blas", action="store_true", help="gemm: also time torch.matmul (hipBLASLt) on the same operands - the "
                     "vendor library as a same-box reference point; never on the product path")
     a = ap.parse_args()
@@ -153,6 +155,8 @@ def main():
                                  ("ff1+gelu", F_, C, {"bias": True, "gelu": True}),
                                  ("ff2+res", C, F_, {"bias": True, "res": True}),
                                  ("skip(2C)", C, 2 * C, {"bias": True})):
+            if a.gemm_names and name not in a.gemm_names.split(","):
+                continue
             A = rnd(R, Kk); W = rnd(Nn, Kk); out = torch.empty((R, Nn), dtype=torch.bfloat16, device=dev)
             if kw.get("gelu"):
                 W = (W.float() * Kk ** -0.5).to(torch.bfloat16)      # unit-variance pre-activations (a linear behind a LayerNorm): the

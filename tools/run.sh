@@ -157,5 +157,22 @@ print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['
 import json; d=json.load(open('gpurun_out/r06c_bench.json')); r=d['roofline']
 print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['nominal']['ms_per_step'], d['latents_fingerprint'])"
     ;;
+  r06d)   # probes: joules per flop of the two bf16 MFMA shapes; the attention kernel at the nominal head count; a kernel
+          # trace of the NOMINAL step (next #2 v); LDS bank conflicts of the ping-pong GEMM per launch shape (next #2 iv)
+    export TMPDIR=/tmp
+    python tools/ubench/mfma_energy.py --seconds 3 --out gpurun_out/r06d_mfma_energy.json 2>&1 | tail -22 | tee gpurun_out/r06d_mfma_energy.txt
+    python tools/kernel_bench.py --shape nominal --only attn,xattn --product-only --reps 5 2>&1 | tail -6 | tee gpurun_out/r06d_attn_nominal.txt
+    python tools/kernel_bench.py --shape headline --only attn,xattn --product-only --reps 5 2>&1 | tail -6 | tee gpurun_out/r06d_attn_headline.txt
+    OUT=$PWD/gpurun_out/prof_r06d_nominal; rm -rf $OUT; mkdir -p $OUT
+    timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python bench.py --shape nominal --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
+    python tools/summarize_prof.py $OUT gpurun_out/r06d_nominal 2>&1 | tail -3
+    head -14 gpurun_out/r06d_nominal_by_launch_shape.csv | cut -c1-200
+    for nm in qkv "ff1+gelu" "ff2+res" "attn-out+res"; do
+      P=$PWD/gpurun_out/prof_r06d_lds_$(echo $nm | tr -d '+()'); rm -rf $P; mkdir -p $P
+      timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES -d $P/pmc_lds -o pmc -- python tools/kernel_bench.py --only gemm --product-only --reps 1 --gemm-names "$nm" > $P/log.txt 2>&1
+      python tools/summarize_prof.py $P gpurun_out/r06d_lds_$(echo $nm | tr -d '+()') 2>&1 | tail -1
+      grep -i gemm256 gpurun_out/r06d_lds_$(echo $nm | tr -d '+()')_pmc.csv | cut -c1-260
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -11,6 +11,13 @@ Stage 0, mesh post-processing / vertex normals (trimesh), GLB export.  Prints on
 BASELINE.json's "end-to-end video->4D wall-clock" restricted to the stages this repository implements).
 
     python tools/e2e_synthetic.py [--frames 16] [--steps 30] [--vertices 50000] [--tiny]
+    python tools/e2e_synthetic.py --config 1      BASELINE.json configs[1]: the 16 davis_camel frames (tests/golden/frames/, preprocessed by the
+                                                  reference's own ImagePreprocessor + BitImageProcessor geometry), 50-step scheduler, bf16
+    python tools/e2e_synthetic.py --config 3      configs[3]: the panda clip; in the reference this path (pipeline_with_3d) differs from configs[1]
+                                                  ONLY in where the anchor latent / mesh come from (a given panda.glb through the TripoSG VAE
+                                                  encoder instead of TripoSG's image-to-3D sampler) - both are Stage 0, on the reference path;
+                                                  here the anchor latent is seeded noise in both, so the two records time the same GPU chain
+Both are PLUMBING records on random-init weights (no checkpoint is reachable offline): not BASELINE's end-to-end metric.
 """
 import argparse
 import json
@@ -69,14 +76,21 @@ def build(tiny: bool, dev):
     return enc, denoiser, vae, HipSchedulerFlow, ClassifierFreeGuidance, n_tokens, window, side
 
 
-def run(frames: int, steps: int, vertices: int, tiny: bool, dev, seed: int = 44):
+def run(frames: int, steps: int, vertices: int, tiny: bool, dev, seed: int = 44, clip: str = None, label: str = None):
     from actionmesh_amd import LatentBank, generate_3d_latents, generate_vertex_animation
     t_build = time.perf_counter()
     enc, denoiser, vae, Sched, CFG, n_tokens, window, side = build(tiny, dev)
     torch.cuda.synchronize(dev)
     t_build = time.perf_counter() - t_build
     g = torch.Generator().manual_seed(1)
-    pixels = torch.randn((frames, 3, side, side), generator=g).to(dev)
+    if clip:           # a real clip as the context encoder receives it (oracle/make_golden_frames.py)
+        import numpy as np
+        from oracle.make_golden_frames import frames_to_pixels          # the rescale + normalise half of BitImageProcessor (data handling only)
+        rgb = np.load(os.path.join(ROOT, "tests", "golden", "frames", f"{clip}_16x224.npz"))["rgb_u8"]
+        assert rgb.shape[0] >= frames and rgb.shape[1] == side, (rgb.shape, frames, side)
+        pixels = frames_to_pixels(rgb[:frames]).to(dev)
+    else:
+        pixels = torch.randn((frames, 3, side, side), generator=g).to(dev)
     timesteps = torch.arange(frames, dtype=torch.float32)
     anchor_latent = torch.randn((1, n_tokens, 64), generator=g).to(dev)
     pts = torch.nn.functional.normalize(torch.randn((vertices, 3), generator=g), dim=-1) * 0.8        # a sphere of radius 0.8
@@ -129,7 +143,10 @@ def run(frames: int, steps: int, vertices: int, tiny: bool, dev, seed: int = 44)
                         "output_files_host_side": round(t_out, 3), "chamfer_metrics": round(t_metric, 4)},
             "output_files_mb": round(out_bytes / 1e6, 1),
             "config": {"workload": f"{frames} frames, {n_win} AR window(s) of {window}, {steps} denoise steps, N={n_tokens} tokens, "
-                                   f"{vertices} vertices, {'tiny' if tiny else 'shipped'} model shapes, random-init weights"}}
+                                   f"{vertices} vertices, {'tiny' if tiny else 'shipped'} model shapes, random-init weights"
+                                   + (f", frames = the reference's {clip} clip" if clip else ", random frames")},
+            **({"baseline_config": label} if label else {}),
+            "context_rms": round(float(context.float().pow(2).mean().sqrt()), 4), "latents_rms": round(float(lat[1:].float().pow(2).mean().sqrt()), 4)}
 
 
 def main():
@@ -138,10 +155,20 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--vertices", type=int, default=50000)
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--clip", default=None, choices=["davis_camel", "panda"], help="frames of a reference example clip (tests/golden/frames/) instead of noise")
+    ap.add_argument("--config", type=int, default=None, choices=[1, 3], help="BASELINE.json configs[1] / configs[3] as a plumbing record (see the module docstring)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    print(json.dumps(run(a.frames, a.steps, a.vertices, a.tiny, dev)))
+    label = None
+    if a.config == 1:
+        a.clip, a.frames, a.steps = "davis_camel", 16, 50
+        label = "configs[1]: davis_camel 16 frames, full 50-step scheduler, bf16, 1 x MI355X - PLUMBING on random-init weights, not the end-to-end metric"
+    elif a.config == 3:
+        a.clip, a.frames, a.steps = "panda", 16, 50
+        label = ("configs[3]: {video+3D}->4D panda path, 16 frames, 1 x MI355X - PLUMBING on random-init weights; differs from configs[1] only in the "
+                 "anchor latent's source (Stage 0, reference path), which is seeded noise in both records")
+    print(json.dumps(run(a.frames, a.steps, a.vertices, a.tiny, dev, clip=a.clip, label=label)))
 
 
 if __name__ == "__main__":

@@ -174,5 +174,19 @@ print({k: d[k] for k in ('value','ms_per_step')}, r['launch_ms'], r['frac'], d['
       grep -i gemm256 gpurun_out/r06d_lds_$(echo $nm | tr -d '+()')_pmc.csv | cut -c1-260
     done
     ;;
+  r06e)   # does the cheaper MFMA shape (r06d: 16x16x32 moves 8 % fewer joules per flop than 32x32x16 in a bare stream) pay INSIDE the 4x64 attention
+          # kernel?  TIMING probe only (tools/gen_attn64_asm.py AM_A64_MFMA16_TIMING: wrong results by construction): P.V phase as 2 x 16x16x32
+    V=$PWD/build/variants
+    for round in 1 2; do for v in base pv16; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee gpurun_out/r06e_pv16_ab.txt
+    for v in base pv16; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06e_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06e_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), 'zero-operand ms', (r['samples'].get('zero operands (diagnostic: same launch, nothing toggles - the schedule\'s rate at the full clock)') or {}).get('launch_ms'))" | tee -a gpurun_out/r06e_pv16_ab.txt
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -60,6 +60,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return __buil
 #ifndef AM_A64_SADDR
 #define AM_A64_SADDR 1
 #endif
+#ifndef AM_A64_SNAKE
+#define AM_A64_SNAKE 0       // operand-order probe of the lazy iteration (see phase 1); bit-identical either way
+#endif
 #ifndef AM_A64_PREP
 #define AM_A64_PREP 1
 #endif
@@ -499,7 +502,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int gap = (kk * 4 + d) * 2;
-        pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
+        // AM_A64_SNAKE (round 6 probe): the two MFMAs of a pair share their A operand (the V^T / K fragment); in the plain order the
+        // step to the next pair changes BOTH operands (A_d, P0) (A_d, P1) (A_d+1, P0) ..., in the snake order - odd pairs run block 1
+        // first - every step changes ONE: (A_d, P0) (A_d, P1) (A_d+1, P1) (A_d+1, P0).  Same per-block accumulation order: same bits.
+        const bool sw1 = AM_A64_SNAKE && (d & 1);
+        if (sw1) pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk])); else pv_mfma(d, vf[kk & 1][d], bf(p0c[kk]));
         POST_PV();
         if (kk == 0) { if (AM_A64_PREP) k_issue(); else dma_k(d); }      // one LDS-DMA piece per MFMA pair
         if (d < 2) {                                            // next fragments in gaps 0..3 of the step: landed by its end
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
           for (int n = ES1.lo[gap]; n < ES1.lo[gap + 1]; ++n) es.step(n, s0[0], s0[1], p0n);
         FENCE();
-        pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
+        if (sw1) pv_mfma(d, vf[kk & 1][d], bf(p0c[kk])); else pv_mfma(4 + d, vf[kk & 1][d], bf(p1[kk]));
         POST_PV();
         if (AM_A64_PREP && kk == 0 && d < 3) k_prep(d + 1);
         if (d < 2) {
@@ -540,16 +547,23 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int gap = (ks * 2 + kb) * 2;
-        if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks % 3][kb], negm[0]);
-        else qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
+        const bool sw2 = AM_A64_SNAKE && (kb & 1);
+        auto qk_j0 = [&]() __attribute__((always_inline)) {
+          if (ks == 0) s0[kb] = qk_mfma_first(ks, kf[ks % 3][kb], negm[0]);
+          else qk_mfma_acc(ks, kf[ks % 3][kb], s0[kb]);
+        };
+        auto qk_j1 = [&]() __attribute__((always_inline)) {
+          if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks % 3][kb], negm[1]);
+          else qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
+        };
+        if (sw2) qk_j1(); else qk_j0();
         POST_QK();
         if (ks < 2) { if (AM_A64_PREP) v_issue(); else dma_v(ks * 2 + kb); }
         if (!(ABL & (8 | 64)))
 #pragma unroll
           for (int n = ES2.lo[gap]; n < ES2.lo[gap + 1]; ++n) es.step(n, s1c[0], s1c[1], p1);
         FENCE();
-        if (ks == 0) s1n[kb] = qk_mfma_first(8 + ks, kf[ks % 3][kb], negm[1]);
-        else qk_mfma_acc(8 + ks, kf[ks % 3][kb], s1n[kb]);
+        if (sw2) qk_j0(); else qk_j1();
         POST_QK();
         if (AM_A64_PREP && ks < 2 && ks * 2 + kb < 3) v_prep(ks * 2 + kb + 1);
         if (ks < 6) kf[(ks + 2) % 3][kb] = k_frag(k_st, kb, ks + 2);      // into the set the previous k-step has finished with

@@ -188,5 +188,20 @@ import json; d=json.load(open('gpurun_out/r06e_bench_$v.json')); r=d['roofline']
 print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), 'zero-operand ms', (r['samples'].get('zero operands (diagnostic: same launch, nothing toggles - the schedule\'s rate at the full clock)') or {}).get('launch_ms'))" | tee -a gpurun_out/r06e_pv16_ab.txt
     done
     ;;
+  r06f)   # operand-order probe of the 4x64 attention kernel (AM_A64_SNAKE: every MFMA step changes ONE operand instead of one-then-both): bits, time, joules
+    V=$PWD/build/variants
+    for v in base snake; do ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_bits.py 2>/dev/null > gpurun_out/r06f_bits_$v.txt; done
+    if cmp -s gpurun_out/r06f_bits_base.txt gpurun_out/r06f_bits_snake.txt; then echo "BIT-IDENTICAL: snake vs plain MFMA order"; else echo "DIFFERENT BITS"; fi | tee gpurun_out/r06f_snake_ab.txt
+    for round in 1 2 3; do for v in base snake; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee -a gpurun_out/r06f_snake_ab.txt
+    for v in base snake base snake; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06f_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06f_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'))" | tee -a gpurun_out/r06f_snake_ab.txt
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

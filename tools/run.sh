@@ -203,5 +203,49 @@ import json; d=json.load(open('gpurun_out/r06f_bench_$v.json')); r=d['roofline']
 print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'))" | tee -a gpurun_out/r06f_snake_ab.txt
     done
     ;;
+  r06final)   # end-of-round evidence for the FINAL sources of round 6: the whole GPU suite, smoke, the driver's own bench command, the profile set named by
+              # the sources sha, the in-model GEMM table, the fp8 lines, configs[1] / [3] plumbing records, configs[4] on one device, N > 1 dry runs
+    TAG=r06
+    timeout 2700 python -m pytest tests -q -m gpu -rA --timeout=600 --durations=40 2>&1 | grep -v "^$" > gpurun_out/${TAG}_gputest_full.txt
+    grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_gputest_full.txt | tail -15 | tee gpurun_out/${TAG}_gputest.txt
+    grep -A42 "slowest 40 durations" gpurun_out/${TAG}_gputest_full.txt | head -44 >> gpurun_out/${TAG}_gputest.txt
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 | tee -a gpurun_out/${TAG}_gputest.txt
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench_headline.json
+    python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_headline.json'))
+r=d['roofline']; c=d['cpu_baseline']
+print({k: d[k] for k in ('value','ms_per_step','dtype','step_frac_of_bf16_peak')}, r['launch_ms'], r['frac'], r['traffic'], r.get('energy_j'), r.get('pj_per_flop'), r.get('effective_clock_ghz'), r.get('pipe_busy'), d.get('nominal',{}).get('ms_per_step'), d['with_exact_shortcuts']['ms_per_step'])
+print('non-attention ms per step', round(d['ms_per_step'] - 21 * r['launch_ms'], 2))
+print('cpu_baseline', c['value'], c['cores'], c['derivation'], c['scaled_reference'], c['fit']['value'], c['fit']['max_relative_residual'])"
+    tools/gpu_profile.sh $TAG 2>&1 | tail -8
+    for sh in headline nominal; do
+      python tools/kernel_bench.py --shape $sh --only gemm,fused --product-only --blas --reps 20 2>&1 | grep -E "^gemm|qkv|^cross" > gpurun_out/${TAG}_gemm_$sh.txt
+    done
+    grep -E "in-model|ablation|256sq-pingpong:|hipBLASLt" gpurun_out/${TAG}_gemm_headline.txt | cut -c1-200
+    for dt in fp8 fp8_fast; do
+      timeout 600 python bench.py --dtype $dt --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_headline_$dt.json
+      timeout 600 python bench.py --shape long64 --dtype $dt --steps 1 --warmup 1 --no-cpu-baseline --no-nominal --no-roofline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_long64_$dt.json
+    done
+    python -c "
+import json
+for f in ('bench_headline_fp8', 'bench_headline_fp8_fast', 'bench_long64_fp8', 'bench_long64_fp8_fast'):
+    d = json.load(open('gpurun_out/${TAG}_' + f + '.json')); print(f, {k: d[k] for k in d if k in ('ms_per_step', 'value', 'dtype', 'step_frac_of_dtype_peak', 'step_tflops_per_gpu')}, (d.get('roofline') or {}).get('launch_ms'), (d.get('roofline') or {}).get('frac'))"
+    for c in 1 3; do
+      python tools/e2e_synthetic.py --config $c 2>/dev/null | tail -1 | tee gpurun_out/${TAG}_config$c.json | cut -c1-600
+    done
+    python tools/e2e_synthetic.py 2>/dev/null | tail -1 | tee gpurun_out/${TAG}_e2e_synthetic.json | cut -c1-420
+    for P in 2 4 8; do
+      timeout 300 python bench.py --emulate-world $P --steps 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_emulate_world_$P.json
+    done
+    timeout 600 python bench.py --shape long64 --dtype fp8 --emulate-world 8 --steps 1 2>/dev/null | tail -1 > gpurun_out/${TAG}_emulate8_long64_fp8.json
+    python -c "
+import json
+for f in ('emulate_world_2', 'emulate_world_4', 'emulate_world_8', 'emulate8_long64_fp8'):
+    d = json.load(open('gpurun_out/${TAG}_' + f + '.json')); print(f, {k: d[k] for k in d if k in ('rank0_ms_per_step', 'modelled_link_ms_per_layer')})"
+    timeout 900 python bench.py --gpus 4 --same-device --steps 20 --warmup 5 --no-roofline 2>gpurun_out/${TAG}_bench4.err | grep "^{" > gpurun_out/${TAG}_bench_same_device_x4_headline.json
+    python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_same_device_x4_headline.json'))
+print('self-launched same-device x4 headline:', d['ms_per_step'], d['exchange_ab'], d['fingerprint_check'], d['launcher']['attempts'])" || tail -5 gpurun_out/${TAG}_bench4.err
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

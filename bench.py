@@ -615,6 +615,17 @@ def preflight_child(args):
     rec["seconds"] = round(time.time() - t0, 2)
     print(json.dumps(rec), flush=True)
     sys.stdout.flush()
+    # the ranks leave TOGETHER: rank 0 is still busy with its single-rank comparison when the others are done, and a communicator whose
+    # peers have vanished is one more thing that could go wrong on first contact with a real node; the wait is bounded
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        st = c10d._get_default_store()
+        if rank == 0:
+            st.set("am_preflight_done", "1")
+        else:
+            st.wait(["am_preflight_done"], timedelta(seconds=60))
+    except Exception:                                # noqa: BLE001 - the verdict is already out
+        pass
     os._exit(0)          # no destroy_process_group: a half-dead back-end must not keep the verdict from leaving
 
 
@@ -711,7 +722,7 @@ def main():
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the seconds-long pre-flight of the exchange back-ends (killable child processes on a plumbing-size "
                          "problem, verdicts in `exchange_ab.preflight`) that keeps a dead back-end from costing a headline warm-up")
-    ap.add_argument("--preflight-timeout", type=float, default=90.0, help="seconds a pre-flight child may take before it is killed")
+    ap.add_argument("--preflight-timeout", type=float, default=120.0, help="seconds a pre-flight child may take before it is killed")
     ap.add_argument("--preflight-child", default=None, choices=["rccl", "peer"], help=argparse.SUPPRESS)
     ap.add_argument("--pf-port", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()

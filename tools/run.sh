@@ -247,5 +247,14 @@ for f in ('emulate_world_2', 'emulate_world_4', 'emulate_world_8', 'emulate8_lon
 import json; d=json.load(open('gpurun_out/${TAG}_bench_same_device_x4_headline.json'))
 print('self-launched same-device x4 headline:', d['ms_per_step'], d['exchange_ab'], d['fingerprint_check'], d['launcher']['attempts'])" || tail -5 gpurun_out/${TAG}_bench4.err
     ;;
+  r06g)   # after the final run: the pre-flight tweak (children leave together) under the multi-rank bench tests, and the driver's own bench command on
+          # another box - now with roofline.traffic resolved from the committed record of this sources sha
+    timeout 900 python -m pytest -q -m gpu --timeout=600 tests/test_multi_gpu.py -k "bench" 2>&1 | tail -3 | tee gpurun_out/r06g_mgpu.txt
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r06g_bench_driver_style.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r06g_bench_driver_style.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step','steps','warmup','step_frac_of_bf16_peak')}, r['launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r.get('energy_j'), d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+print('non-attention ms per step', round(d['ms_per_step'] - 21 * r['launch_ms'], 2))"
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

@@ -120,6 +120,14 @@ def main():
                 continue
             print(f"cross-attn BT={BT} H={H} L={L} S={S} variant={d:3d} ({nm:8s}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
         del Q, K, Vt, out
+    if "xsweep" in only:       # cross-attention launch vs the number of context tokens: what is per-workgroup overhead, what is per key tile
+        BT = B * T
+        Q = rnd(BT, H, ops.round_up(L, 256), 128); out = torch.empty((BT * L, C), dtype=torch.bfloat16, device=dev)
+        for Sx in (1, 64, 128, 192, 256, 257, 320, 512):
+            K = rnd(BT, H, ops.round_up(Sx, 64), 128); Vt = rnd(BT, H, 128, ops.round_up(Sx, 64))
+            ms = timeit(lambda: ops.attention(Q, K, Vt, L, Sx, out=out, defer_log2=a.defer), a.reps)
+            print(f"cross-attn sweep BT={BT} H={H} L={L} S={Sx:4d} ({ops.round_up(Sx, 64) // 64} key tiles): {ms:8.3f} ms")
+        del Q, out
     if "fused" in only:          # the QKV linear + head split: one launch (am_gemm_headpost_bf16) vs two
         L_ = N + 1
         z = rnd(R, C); wqkv = rnd(3 * C, C)

@@ -346,6 +346,264 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
 }
 
 // ===========================================================================
+// Cross-attention with the WHOLE key stream resident in LDS (round 6).  The per-frame cross-attention reads S = 257 context tokens
+// (pipeline.py:665-667: DINOv2's class token + 256 patches; attention_processor.py:94-115) for L = N + 1 query rows per (frame, head):
+// the tile-streaming kernel above gives every 128-row query block its own prologue (Q fragments, the first K / V^T tile in flight), five
+// barriers and a fifth key tile that holds ONE key - at the headline shape 8448 workgroups of ~15 us for 5 us of MFMAs each.  Here ONE
+// workgroup per (frame, head) loads K and V^T once - the full 64-key tiles (at most 4) plus a SHORT tail tile of at most 16 keys -
+// and then walks all the query blocks of its sequence against LDS that nobody writes any more: no barrier and no DMA wait in the
+// loop, the next block's Q rows are fetched while the current block computes, and the tail costs 8 + 4 MFMAs instead of 32 (its QK^T
+// only multiplies key block 0, its P.V only the first 16-key step; padded keys score 0 and meet zero V^T columns, as everywhere).
+// Same layouts, same LDS images, same per-tile arithmetic as attn_fwd_kernel (its sub_tile, copied: that kernel's tuning is not
+// touched); the tail's row-sum correction counts 31 padded keys instead of 63, so results agree to rounding, not bit for bit.
+// LDS: n_full x (16 + 16) KiB + 8 KiB (32 K rows) + 16 KiB (one V^T tile image, first 16 key columns used) <= 152 KiB: one workgroup
+// of 8 waves per CU.
+// ===========================================================================
+constexpr int RES_MAX_FULL = 4;
+constexpr int RES_TAIL_MAX = 16;
+template <int DEFER>
+__global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, int n_full, int tail_valid, int n_qblk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ks = smem;                                    // [n_full][SUB_B]
+  unsigned char* Vs = smem + n_full * SUB_B;                   // [n_full][SUB_B]
+  unsigned char* Kt = smem + 2 * n_full * SUB_B;               // tail: rows 0..31 of the K tile image (8 KiB)
+  unsigned char* Vt_ = Kt + SUB_B / 2;                         // tail: the V^T tile image (16 KiB)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.x;                                   // sequence * heads + head
+  const int head = bh % p.heads, seq = bh / p.heads;
+  const float c = p.scale * 1.4426950408889634f;
+
+  // ---- the key stream -> LDS, once: unit U = j * 512 + tid of a 1024-unit sub-tile operand (same images as attn_fwd_kernel) ----
+  {
+    const int64_t k_seq_stride = (int64_t)p.sk_pad * HD;
+    const bf16_t* kb = p.K + (int64_t)bh * k_seq_stride;
+    const bf16_t* vb = p.Vt + (int64_t)bh * k_seq_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int U = j * 512 + tid;
+      const int kr = U >> 4, kc = (U & 15) ^ (kr & 15);
+      const int vr = U >> 3, vc = (U & 7) ^ ((vr >> 1) & 7);
+      const bf16_t* ks = kb + kr * HD + kc * 8;
+      const bf16_t* vs = vb + (int64_t)vr * p.sk_pad + vc * 8;
+      const int ub = (j * 512 + wave * 64) * 16;
+      for (int t = 0; t < n_full; ++t) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + (int64_t)t * (KVBLK * HD)), (lds_ptr_t)(Ks + t * SUB_B + ub), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + (int64_t)t * KVBLK), (lds_ptr_t)(Vs + t * SUB_B + ub), 16, 0, 0);
+      }
+      if (tail_valid > 0) {
+        if (j == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + (int64_t)n_full * (KVBLK * HD)), (lds_ptr_t)(Kt + ub), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + (int64_t)n_full * KVBLK), (lds_ptr_t)(Vt_ + ub), 16, 0, 0);
+      }
+    }
+  }
+
+  // fragment read offsets (bytes) inside a sub-tile
+  int k_off[8], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = l31 * 256 + (((ks * 2 + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) v_off[kk] = l31 * 128 + (((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 4);
+  auto max3 = [](float a, float b, float cc) __attribute__((always_inline)) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(cc));
+    return d;
+  };
+  f32x16_t zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+  // padded keys among the ones this lane holds of the tail's key block 0 (keys (r & 3) + 8 (r >> 2) + 4 hi, r = 0 .. 15)
+  int tail_pad = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) tail_pad += min(4, max(0, 8 * g + 4 * hi + 4 - tail_valid));
+
+  // raw Q rows of the first block (the scaling to log2 units happens at the top of the block's iteration)
+  u32x4_t qraw[8];
+  auto q_fetch = [&](int qb) __attribute__((always_inline)) {
+    const bf16_t* qp = p.Q + ((int64_t)bh * p.sq_pad + qb * 256 + wave * 32 + l31) * HD + hi * 8;      // sq_pad % 256 == 0: always in bounds
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qraw[ks] = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
+  };
+  q_fetch(0);
+  dma_drain_barrier();                                         // the key stream has landed and is visible to every wave
+
+  for (int qb = 0; qb < n_qblk; ++qb) {
+    bf16x8_t qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4_t sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc[e] = pack_bf2(bflo(qraw[ks][e]) * c, bfhi(qraw[ks][e]) * c);
+      qf[ks] = __builtin_bit_cast(bf16x8_t, sc);
+    }
+    if (qb + 1 < n_qblk) q_fetch(qb + 1);                     // in flight under this block's tiles
+    f32x16_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    bool first = true;
+
+    // the deferred re-base of the online softmax (attn_fwd_kernel): mx = this tile's row max
+    auto rebase = [&](float mx) __attribute__((always_inline)) {
+      mx -= m_run;
+      if (first || !__all(mx <= (float)DEFER)) {
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+        first = false;
+        m_run += delta;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
+    };
+    // ---- full 64-key tiles: attn_fwd_kernel's sub_tile, operands from the resident images ----
+    for (int t = 0; t < n_full; ++t) {
+      const unsigned char* kp = Ks + t * SUB_B;
+      const unsigned char* vp = Vs + t * SUB_B;
+      f32x16_t s[2];
+      {
+        bf16x8_t kf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + k_off[ks]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          s[0] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[0]);
+          kf[ks] = *reinterpret_cast<const bf16x8_t*>(kp + 32 * 256 + k_off[ks]);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) s[1] = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s[1]);
+      }
+      bf16x8_t vf[8];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk]);
+      asm volatile("s_nop 15" : "+v"(s[0]), "+v"(s[1]));        // MFMA results landed before the VALU reads them
+      float mxa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mxa[i] = max3(s[0][i], s[1][i], s[0][i + 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 4], s[0][i + 8]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 8], s[0][i + 12]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mxa[i] = max3(mxa[i], s[1][i + 12], mxa[i]);
+      float mx = max3(mxa[0], mxa[1], max3(mxa[2], mxa[3], mxa[3]));
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+      }
+      rebase(mx);
+      const f32x2_t m2 = {m_run, m_run};
+      f32x2_t rsa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rsa[i] = f32x2_t{0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t x = f32x2_t{s[kb][r], s[kb][r + 1]} - m2;
+          const f32x2_t pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          s[kb][r] = pp[0];
+          s[kb][r + 1] = pp[1];
+          rsa[(r >> 1) & 3] += pp;
+        }
+      {
+        const f32x2_t rs = (rsa[0] + rsa[1]) + (rsa[2] + rsa[3]);
+        l_run += rs[0] + rs[1];
+      }
+      bf16x8_t pf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf2(s[kk >> 1][(kk & 1) * 8 + 2 * e], s[kk >> 1][(kk & 1) * 8 + 2 * e + 1]);
+        pf[kk] = __builtin_bit_cast(bf16x8_t, w);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          o[d] = AM_MFMA_32x32x16(vf[kk * 4 + d], pf[kk], o[d]);
+          vf[kk * 4 + d] = *reinterpret_cast<const bf16x8_t*>(vp + d * 32 * 128 + v_off[kk + 2]);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 2; kk < 4; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = AM_MFMA_32x32x16(vf[(kk - 2) * 4 + d], pf[kk], o[d]);
+    }
+    // ---- the short tail: key block 0 of its tile only (keys 0 .. 31, of which tail_valid <= 16 are real), one 16-key P.V step ----
+    if (tail_valid > 0) {
+      f32x16_t s0;
+      {
+        bf16x8_t kf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(Kt + k_off[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) s0 = AM_MFMA_32x32x16(kf[ks], qf[ks], ks == 0 ? zero16 : s0);
+      }
+      bf16x8_t vf[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) vf[d] = *reinterpret_cast<const bf16x8_t*>(Vt_ + d * 32 * 128 + v_off[0]);
+      asm volatile("s_nop 15" : "+v"(s0));
+      float mxa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mxa[i] = max3(s0[i], s0[i + 4], s0[i + 8]);
+      float mx = max3(max3(mxa[0], mxa[1], mxa[2]), mxa[3], max3(s0[12], s0[13], max3(s0[14], s0[15], s0[15])));
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+      }
+      rebase(mx);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_run);
+        rs += s0[r];
+      }
+      l_run += rs - (float)tail_pad * __builtin_amdgcn_exp2f(-m_run);      // the padded keys scored exactly 0
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = pack_bf2(s0[2 * e], s0[2 * e + 1]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, w);                  // k-slots of the first 16-key step (keys 0 .. 15 in perm16 order)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = AM_MFMA_32x32x16(vf[d], pf, o[d]);
+    }
+    // ---- epilogue of the block: O[q][head * 128 + d] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = qb * 256 + wave * 32 + l31;
+    if (q < p.sq) {
+      bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2_t w;
+          w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+          w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
+        }
+    }
+  }
+}
+
+// ===========================================================================
 // Balanced two-phase schedule.  The two half-workgroups (waves 0-3 / 4-7; wave i and wave i+4 share
 // SIMD i) run exactly one phase apart - waves 4-7 take one extra barrier before the loop, waves 0-3 one
 // after it - and a 64-key tile is cut into two phases of EQUAL weight, separated by barriers:
@@ -704,6 +962,31 @@ int launch(const am_attn_args* a, void* stream) {
 
 }  // namespace
 
+// The resident-key-stream kernel (attn_resident_kernel) takes the launches it was built for: one key chunk of at most 4 full tiles plus a
+// tail of at most 16 keys (the cross-attention's 257 context tokens), at least 4 query blocks per (sequence, head) to walk and at least
+// half a chip of (sequence, head) pairs; everything else - the encoders' 257-row sequences, tests with odd shapes - stays on the
+// tile-streaming kernel.  ACTIONMESH_AMD_XATTN_RESIDENT=0 turns it off (same-box A/B).
+static bool resident_eligible(const am_attn_args* a) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("ACTIONMESH_AMD_XATTN_RESIDENT"); on = (e && e[0] == '0') ? 0 : 1; }
+  const int n_full = a->sk / KVBLK, tail = a->sk % KVBLK;
+  return on == 1 && a->nchunks == 1 && a->state_mode == 0 && a->chunk_total == 0 && n_full >= 1 && n_full <= RES_MAX_FULL && tail <= RES_TAIL_MAX &&
+         a->sk_pad >= (n_full + (tail > 0 ? 1 : 0)) * KVBLK && ceil_div(a->sq, 256) >= 4 && (int64_t)a->nseq * a->heads >= 128;
+}
+template <int DEFER>
+static int launch_resident(const am_attn_args* a, void* stream) {
+  const int n_full = a->sk / KVBLK, tail = a->sk % KVBLK;
+  const int smem_bytes = 2 * n_full * SUB_B + (tail > 0 ? SUB_B / 2 + SUB_B : 0);
+  AM_ONCE_PER_DEVICE({
+    AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<DEFER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * RES_MAX_FULL * SUB_B + SUB_B / 2 + SUB_B));
+  });
+  hipLaunchKernelGGL((attn_resident_kernel<DEFER>), dim3(a->nseq * a->heads), dim3(512), smem_bytes, (hipStream_t)stream, *a, n_full, tail,
+                     ceil_div(a->sq, 256));
+  AM_HIP(hipGetLastError());
+  return AM_OK;
+}
+
 #ifdef AM_ATTN_ABLATIONS
 int am_attention_variant(const am_attn_args* a, void* stream);   // am_attention_variants.hip
 #endif
@@ -743,6 +1026,8 @@ extern "C" int am_attention_bf16(const am_attn_args* a, void* stream) {
   // mostly prologue (Q fragments, the first K / V^T tiles in flight) and epilogue, and the second resident workgroup covers them.
   // Same arithmetic per row: bit-identical output; 15-18 % faster at the cross shapes (profiles/r04y_cross_attn_geometry.txt).
   const bool short_stream = a->rows == 0 && (int64_t)ceil_div(a->sk, KVBLK) * a->nchunks < 16;
+  if (short_stream && (a->defer_log2 == 0 || a->defer_log2 == 8) && resident_eligible(a))
+    return a->defer_log2 == 0 ? launch_resident<0>(a, stream) : launch_resident<8>(a, stream);
   switch (a->defer_log2) {
     case 0: return short_stream ? launch<0, 4, 1>(a, stream) : launch<0, 8, 2, 3>(a, stream);
     case 8: return short_stream ? launch<8, 4, 1>(a, stream) : launch<8, 8, 2, 3>(a, stream);

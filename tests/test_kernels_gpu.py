@@ -678,3 +678,36 @@ def test_add_layernorm_f32(dtype, C):
     assert ops.add_layernorm_f32(h2, y) is None and torch.equal(h2, h_ref)          # accumulate only
     z3 = ops.add_layernorm_f32(h_ref.clone(), None, w, b, dtype=dtype)              # LayerNorm only: the same bits
     assert torch.equal(z3, z)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("defer", [0, 8])
+@pytest.mark.parametrize("nseq,H,sq,sk", [(16, 8, 1100, 257),      # the cross-attention's context: 4 full tiles + ONE key
+                                          (32, 4, 1024, 256),      # no tail at all
+                                          (16, 8, 1500, 65),       # one tile + one key
+                                          (16, 8, 1030, 144),      # two tiles + the longest short tail (16 keys)
+                                          (64, 2, 2049, 257)])
+def test_cross_attention_with_the_resident_key_stream(dev, nseq, H, sq, sk, defer, dtype):
+    """Round 6: launches of the cross-attention family (one key chunk of <= 4 full tiles + a tail of <= 16 keys, >= 4 query blocks per
+    (sequence, head), >= 128 pairs) run attn_resident_kernel - the key stream loaded into LDS once per (sequence, head), every query
+    block walked against it without a barrier, the tail as 8 + 4 MFMAs.  Against the fp32 statement (the attention kernels' own
+    tolerance), and against the tile-streaming kernel forced through its geometry code (defer 50 / 58: never the resident path): the two
+    differ only in the tail's padded-key correction, i.e. by rounding."""
+    from actionmesh_amd import ops
+    q = (_randn((nseq, H, sq, 128), 11, dev) * 1.3).to(dtype)
+    k = _randn((nseq, H, sk, 128), 12, dev).to(dtype)
+    v = _randn((nseq, H, sk, 128), 13, dev).to(dtype)
+    sq_pad, sk_pad = ops.round_up(sq, 256), ops.round_up(sk, 64)
+    Q = torch.zeros((nseq, H, sq_pad, 128), dtype=dtype, device=dev); Q[:, :, :sq] = q
+    K = torch.zeros((1, nseq, H, sk_pad, 128), dtype=dtype, device=dev); K[0, :, :, :sk] = k
+    vp = torch.zeros((nseq, H, sk_pad, 128), dtype=dtype, device=dev); vp[:, :, :sk] = v
+    Vt = vp[:, :, ops.perm16_index(sk_pad, dev)].transpose(-1, -2).contiguous()[None]
+    out = ops.attention(Q, K, Vt, sq, sk, defer_log2=defer)
+    streamed = ops.attention(Q, K, Vt, sq, sk, defer_log2=50 + defer)
+    torch.cuda.synchronize()
+    ref = _sdpa_ref(q, k, v).permute(0, 2, 1, 3).reshape(nseq * sq, H * 128)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    _attn_close(out, ref, f"resident cross-attention defer={defer}", rel_tol=tol)
+    d = ((out.float() - streamed.float()).norm() / streamed.float().norm()).item()
+    assert d <= (3e-3 if dtype == torch.bfloat16 else 4e-4), d
+    assert torch.equal(out, ops.attention(Q, K, Vt, sq, sk, defer_log2=defer)), "same inputs, same bits"

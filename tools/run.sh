@@ -256,5 +256,21 @@ import json; d=json.load(open('gpurun_out/r06g_bench_driver_style.json')); r=d['
 print({k: d[k] for k in ('value','ms_per_step','steps','warmup','step_frac_of_bf16_peak')}, r['launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r.get('energy_j'), d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
 print('non-attention ms per step', round(d['ms_per_step'] - 21 * r['launch_ms'], 2))"
     ;;
+  r06h)   # the resident-key-stream cross-attention kernel: tests, the key-count sweep with and without it, same-box step A/B
+    PT="python -m pytest -q -m gpu --timeout=600"
+    timeout 1500 $PT tests/test_kernels_gpu.py -k "attention" 2>&1 | tail -4 | tee gpurun_out/r06h_tests.txt
+    timeout 1500 $PT tests/test_baseline_arch_gpu.py tests/test_denoiser_gpu.py tests/test_f16_gpu.py -x 2>&1 | tail -4 | tee -a gpurun_out/r06h_tests.txt
+    for r in 0 1; do
+      echo "=== ACTIONMESH_AMD_XATTN_RESIDENT=$r"
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r python tools/kernel_bench.py --shape headline --only xsweep --reps 10 2>&1 | grep "sweep"
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r python tools/kernel_bench.py --shape nominal --only xsweep --reps 10 2>&1 | grep "S= 257"
+    done | tee gpurun_out/r06h_xsweep.txt
+    for r in 0 1 0 1; do
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/r06h_bench_res$r.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06h_bench_res$r.json'))
+print('resident=$r:', d['ms_per_step'], d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06h_xsweep.txt
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

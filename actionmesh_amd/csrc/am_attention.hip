@@ -62,6 +62,8 @@
 // Multi-GPU: K/V arrive as `nchunks` frame shards ([chunk][seq][head]...);
 // softmax is permutation-invariant over keys, so chunks are simply
 // concatenated tile streams, each with its own valid-key count.
+#include <algorithm>
+
 #include "am_common.h"
 
 namespace {
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
 constexpr int RES_MAX_FULL = 4;
 constexpr int RES_TAIL_MAX = 16;
 template <int DEFER>
-__global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, int n_full, int tail_valid, int n_qblk) {
+__global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, int n_full, int tail_valid, int n_qblk_total, int qblk_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;                                    // [n_full][SUB_B]
   unsigned char* Vs = smem + n_full * SUB_B;                   // [n_full][SUB_B]
@@ -376,6 +378,11 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
   const int bh = blockIdx.x;                                   // sequence * heads + head
   const int head = bh % p.heads, seq = bh / p.heads;
   const float c = p.scale * 1.4426950408889634f;
+  // few (sequence, head) pairs (a rank's share of a sharded run): the query blocks of a pair are cut over gridDim.y workgroups, each
+  // with its own copy of the key stream (loading it is ~3 us, a query block ~5)
+  const int qb_begin = blockIdx.y * qblk_per_wg;
+  const int qb_end = min(n_qblk_total, qb_begin + qblk_per_wg);
+  if (qb_begin >= qb_end) return;
 
   // ---- the key stream -> LDS, once: unit U = j * 512 + tid of a 1024-unit sub-tile operand (same images as attn_fwd_kernel) ----
   {
@@ -427,11 +434,8 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qraw[ks] = *reinterpret_cast<const u32x4_t*>(qp + ks * 16);
   };
-  q_fetch(0);
-  dma_drain_barrier();                                         // the key stream has landed and is visible to every wave
-
-  for (int qb = 0; qb < n_qblk; ++qb) {
-    bf16x8_t qf[8];
+  bf16x8_t qf[8];
+  auto q_scale = [&]() __attribute__((always_inline)) {        // raw rows -> B-operand fragments in log2 units
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       u32x4_t sc;
@@ -439,7 +443,17 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
       for (int e = 0; e < 4; ++e) sc[e] = pack_bf2(bflo(qraw[ks][e]) * c, bfhi(qraw[ks][e]) * c);
       qf[ks] = __builtin_bit_cast(bf16x8_t, sc);
     }
-    if (qb + 1 < n_qblk) q_fetch(qb + 1);                     // in flight under this block's tiles
+  };
+  q_fetch(qb_begin);
+  dma_drain_barrier();                                         // the key stream has landed and is visible to every wave (and so have the Q rows)
+  q_scale();
+  if (qb_begin + 1 < qb_end) q_fetch(qb_begin + 1);
+
+  // Software pipeline over the query blocks: while block qb computes, the raw rows of block qb + 1 are in flight; they are scaled into
+  // `qf` behind block qb's last MFMA and the rows of block qb + 2 are requested BEFORE block qb's output stores are issued - so the
+  // wait in front of q_scale() covers loads and stores that are a whole block old, never the stores just issued (round 6: with the
+  // scaling at the loop top every block waited for its predecessor's 16 stores to complete, ~10 us per block for 0.5 us of MFMAs).
+  for (int qb = qb_begin; qb < qb_end; ++qb) {
     f32x16_t o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -584,11 +598,13 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
 #pragma unroll
       for (int d = 0; d < 4; ++d) o[d] = AM_MFMA_32x32x16(vf[d], pf, o[d]);
     }
-    // ---- epilogue of the block: O[q][head * 128 + d] ----
+    // ---- the next block's Q (its loads are a block old), the request for the one after, then this block's output ----
+    if (qb + 1 < qb_end) q_scale();
+    if (qb + 2 < qb_end) q_fetch(qb + 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = qb * 256 + wave * 32 + l31;
-    if (q < p.sq) {
+    if (q < p.sq) {       // O[q][head * 128 + d]
       bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
 #pragma unroll
       for (int d = 0; d < 4; ++d)
@@ -964,14 +980,15 @@ int launch(const am_attn_args* a, void* stream) {
 
 // The resident-key-stream kernel (attn_resident_kernel) takes the launches it was built for: one key chunk of at most 4 full tiles plus a
 // tail of at most 16 keys (the cross-attention's 257 context tokens), at least 4 query blocks per (sequence, head) to walk and at least
-// half a chip of (sequence, head) pairs; everything else - the encoders' 257-row sequences, tests with odd shapes - stays on the
+// two rounds' worth of query blocks in the launch; everything else - the encoders' 257-row sequences, tests with odd shapes - stays on the
 // tile-streaming kernel.  ACTIONMESH_AMD_XATTN_RESIDENT=0 turns it off (same-box A/B).
 static bool resident_eligible(const am_attn_args* a) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("ACTIONMESH_AMD_XATTN_RESIDENT"); on = (e && e[0] == '0') ? 0 : 1; }
   const int n_full = a->sk / KVBLK, tail = a->sk % KVBLK;
   return on == 1 && a->nchunks == 1 && a->state_mode == 0 && a->chunk_total == 0 && n_full >= 1 && n_full <= RES_MAX_FULL && tail <= RES_TAIL_MAX &&
-         a->sk_pad >= (n_full + (tail > 0 ? 1 : 0)) * KVBLK && ceil_div(a->sq, 256) >= 4 && (int64_t)a->nseq * a->heads >= 128;
+         a->sk_pad >= (n_full + (tail > 0 ? 1 : 0)) * KVBLK && ceil_div(a->sq, 256) >= 4 && (int64_t)a->nseq * a->heads * ceil_div(a->sq, 256) >= 512 &&
+         (int64_t)a->nseq * a->heads <= 65535;
 }
 template <int DEFER>
 static int launch_resident(const am_attn_args* a, void* stream) {
@@ -981,8 +998,14 @@ static int launch_resident(const am_attn_args* a, void* stream) {
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<DEFER>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                2 * RES_MAX_FULL * SUB_B + SUB_B / 2 + SUB_B));
   });
-  hipLaunchKernelGGL((attn_resident_kernel<DEFER>), dim3(a->nseq * a->heads), dim3(512), smem_bytes, (hipStream_t)stream, *a, n_full, tail,
-                     ceil_div(a->sq, 256));
+  // one workgroup per CU (the LDS image): aim at a grid of about one round of the chip - whole (sequence, head) pairs when there are
+  // enough of them, otherwise each pair's query blocks cut over `qsplit` workgroups of at least two blocks
+  const int bh = a->nseq * a->heads, nblk = ceil_div(a->sq, 256);
+  int qsplit = 1;
+  if (bh < 192) qsplit = std::max(1, std::min(nblk / 2, 256 / bh));
+  const int per = ceil_div(nblk, qsplit);
+  hipLaunchKernelGGL((attn_resident_kernel<DEFER>), dim3(bh, ceil_div(nblk, per)), dim3(512), smem_bytes, (hipStream_t)stream, *a, n_full, tail,
+                     nblk, per);
   AM_HIP(hipGetLastError());
   return AM_OK;
 }

@@ -288,5 +288,9 @@ import json; d=json.load(open('gpurun_out/r06i_bench_res$r.json'))
 print('resident=$r:', d['ms_per_step'], d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06i_xsweep.txt
     done
     ;;
+  r06j)   # where the exact e4m3 attention's tile time goes, on this round's build ("or an ablation table that shows the floor"):
+          # the product (free-running) kernel's timing ablations + the 8-wave form's, same box
+    ACTIONMESH_AMD_LIB=$PWD/build/variants/libam_fp8prof.so python tools/kernel_bench.py --only attn --product-only --fp8 --ablate-fp8 --reps 3 2>&1 | grep -E "fp8|self-attn" | tee gpurun_out/r06j_fp8_ablations.txt
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

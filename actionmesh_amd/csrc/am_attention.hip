@@ -358,18 +358,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(am_attn_args p, in
 // only multiplies key block 0, its P.V only the first 16-key step; padded keys score 0 and meet zero V^T columns, as everywhere).
 // Same layouts, same LDS images, same per-tile arithmetic as attn_fwd_kernel (its sub_tile, copied: that kernel's tuning is not
 // touched); the tail's row-sum correction counts 31 padded keys instead of 63, so results agree to rounding, not bit for bit.
-// LDS: n_full x (16 + 16) KiB + 8 KiB (32 K rows) + 16 KiB (one V^T tile image, first 16 key columns used) <= 152 KiB: one workgroup
-// of 8 waves per CU.
+// The output rows leave through a 2 KiB staging slice per wave (one 32-channel block at a time, XOR-swizzled 8-byte units): the MFMA
+// layout holds one query row per lane, so direct stores were 8-byte pieces of 32 different rows per instruction - 512 line touches per
+// block and wave, the floor of the first form of this kernel; staged, a store instruction writes 64 contiguous bytes of 16 rows.
+// LDS: n_full x (16 + 16) KiB + 8 KiB (32 K rows of the tail) + 4 KiB (the tail's V^T, 16 key columns, compact) + 16 KiB (output staging)
+// <= 156 KiB: one workgroup of 8 waves per CU.
 // ===========================================================================
 constexpr int RES_MAX_FULL = 4;
 constexpr int RES_TAIL_MAX = 16;
+constexpr int RES_VT_TAIL_B = 128 * 16 * 2;      // the tail's V^T, compact
+constexpr int RES_STAGE_B = 8 * 2048;            // output staging, 2 KiB per wave
 template <int DEFER>
 __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, int n_full, int tail_valid, int n_qblk_total, int qblk_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;                                    // [n_full][SUB_B]
   unsigned char* Vs = smem + n_full * SUB_B;                   // [n_full][SUB_B]
   unsigned char* Kt = smem + 2 * n_full * SUB_B;               // tail: rows 0..31 of the K tile image (8 KiB)
-  unsigned char* Vt_ = Kt + SUB_B / 2;                         // tail: the V^T tile image (16 KiB)
+  unsigned char* Vt_ = Kt + SUB_B / 2;                         // tail: V^T [128 d][16 key positions] compact, 32 B per row (4 KiB)
+  unsigned char* Os = Vt_ + RES_VT_TAIL_B;                     // output staging: 2 KiB per wave
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -401,9 +407,12 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + (int64_t)t * (KVBLK * HD)), (lds_ptr_t)(Ks + t * SUB_B + ub), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + (int64_t)t * KVBLK), (lds_ptr_t)(Vs + t * SUB_B + ub), 16, 0, 0);
       }
-      if (tail_valid > 0) {
-        if (j == 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + (int64_t)n_full * (KVBLK * HD)), (lds_ptr_t)(Kt + ub), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vs + (int64_t)n_full * KVBLK), (lds_ptr_t)(Vt_ + ub), 16, 0, 0);
+      if (tail_valid > 0 && j == 0) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ks + (int64_t)n_full * (KVBLK * HD)), (lds_ptr_t)(Kt + ub), 16, 0, 0);
+        if (wave < 4) {        // 256 units: unit tid = (d = tid >> 1, the 8 key positions 8 (tid & 1) .. of the tail's first 16)
+          const bf16_t* vt = vb + (int64_t)(tid >> 1) * p.sk_pad + (int64_t)n_full * KVBLK + (tid & 1) * 8;
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)vt, (lds_ptr_t)(Vt_ + wave * 1024), 16, 0, 0);
+        }
       }
     }
   }
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
       }
       bf16x8_t vf[4];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) vf[d] = *reinterpret_cast<const bf16x8_t*>(Vt_ + d * 32 * 128 + v_off[0]);
+      for (int d = 0; d < 4; ++d) vf[d] = *reinterpret_cast<const bf16x8_t*>(Vt_ + ((d * 32 + l31) * 2 + hi) * 16);
       asm volatile("s_nop 15" : "+v"(s0));
       float mxa[4];
 #pragma unroll
@@ -603,18 +612,33 @@ __global__ __launch_bounds__(512, 2) void attn_resident_kernel(am_attn_args p, i
     if (qb + 2 < qb_end) q_fetch(qb + 2);
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    const int q = qb * 256 + wave * 32 + l31;
-    if (q < p.sq) {       // O[q][head * 128 + d]
-      bf16_t* op = p.O + ((int64_t)seq * p.sq + q) * p.ldo + head * HD + 4 * hi;
+    // staged through this wave's 2 KiB slice, one 32-channel block at a time: row r = 64 B = 8 units of 8 B, unit u at u ^ ((r >> 2) & 7)
+    // (write: the lane's row l31, units 2 g + hi - conflict free; read-back: lane = (row lane >> 2, 16-byte chunk lane & 3)); the
+    // wave's own LDS operations execute in order, the asm statements keep the compiler from re-ordering them
+    unsigned char* st = Os + wave * 2048;
+    const int sw_w = (l31 >> 2) & 7;
+    const int rr = lane >> 2, rc = lane & 3;                   // read-back: rows rr and rr + 16, chunk rc
+    const int64_t row0 = (int64_t)seq * p.sq + qb * 256 + wave * 32;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < 4; ++d) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2_t w;
-          w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
-          w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-          *reinterpret_cast<u32x2_t*>(op + d * 32 + 8 * g) = w;
-        }
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf2(o[d][4 * g] * inv, o[d][4 * g + 1] * inv);
+        w[1] = pack_bf2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(st + l31 * 64 + (((2 * g + hi) ^ sw_w) << 3)) = w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rr + 16 * h;
+        const int k = (r >> 2) & 7;
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(st + r * 64 + ((rc ^ (k >> 1)) << 4));
+        if (k & 1) v = u32x4_t{v[2], v[3], v[0], v[1]};
+        if (qb * 256 + wave * 32 + r < p.sq)
+          *reinterpret_cast<u32x4_t*>(p.O + (row0 + r) * p.ldo + head * HD + d * 32 + rc * 8) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
 }
@@ -988,15 +1012,15 @@ static bool resident_eligible(const am_attn_args* a) {
   const int n_full = a->sk / KVBLK, tail = a->sk % KVBLK;
   return on == 1 && a->nchunks == 1 && a->state_mode == 0 && a->chunk_total == 0 && n_full >= 1 && n_full <= RES_MAX_FULL && tail <= RES_TAIL_MAX &&
          a->sk_pad >= (n_full + (tail > 0 ? 1 : 0)) * KVBLK && ceil_div(a->sq, 256) >= 4 && (int64_t)a->nseq * a->heads * ceil_div(a->sq, 256) >= 512 &&
-         (int64_t)a->nseq * a->heads <= 65535;
+         (int64_t)a->nseq * a->heads <= 65535 && a->ldo % 8 == 0 && (uintptr_t)a->O % 16 == 0;      // 16-byte output stores
 }
 template <int DEFER>
 static int launch_resident(const am_attn_args* a, void* stream) {
   const int n_full = a->sk / KVBLK, tail = a->sk % KVBLK;
-  const int smem_bytes = 2 * n_full * SUB_B + (tail > 0 ? SUB_B / 2 + SUB_B : 0);
+  const int smem_bytes = 2 * n_full * SUB_B + SUB_B / 2 + RES_VT_TAIL_B + RES_STAGE_B;
   AM_ONCE_PER_DEVICE({
     AM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<DEFER>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * RES_MAX_FULL * SUB_B + SUB_B / 2 + SUB_B));
+                               2 * RES_MAX_FULL * SUB_B + SUB_B / 2 + RES_VT_TAIL_B + RES_STAGE_B));
   });
   // one workgroup per CU (the LDS image): aim at a grid of about one round of the chip - whole (sequence, head) pairs when there are
   // enough of them, otherwise each pair's query blocks cut over `qsplit` workgroups of at least two blocks

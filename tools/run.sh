@@ -272,6 +272,22 @@ import json; d=json.load(open('gpurun_out/r06h_bench_res$r.json'))
 print('resident=$r:', d['ms_per_step'], d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06h_xsweep.txt
     done
     ;;
+  r06k)   # resident cross-attention, third form (output staged through LDS: 64-byte store segments; compact tail V^T): tests + sweep + step A/B
+    PT="python -m pytest -q -m gpu --timeout=600"
+    timeout 900 $PT tests/test_kernels_gpu.py -k "resident or test_attention" 2>&1 | tail -3 | tee gpurun_out/r06k_tests.txt
+    timeout 1200 $PT tests/test_baseline_arch_gpu.py -k "full or forward" tests/test_denoiser_gpu.py -k "full_size or forward or sharded or world" tests/test_f16_gpu.py 2>&1 | tail -3 | tee -a gpurun_out/r06k_tests.txt
+    for r in 0 1; do
+      echo "=== ACTIONMESH_AMD_XATTN_RESIDENT=$r"
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r python tools/kernel_bench.py --shape headline --only xsweep --reps 10 2>&1 | grep "sweep"
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r python tools/kernel_bench.py --shape nominal --only xsweep --reps 10 2>&1 | grep "S= 257"
+    done | tee gpurun_out/r06k_xsweep.txt
+    for r in 0 1 0 1; do
+      ACTIONMESH_AMD_XATTN_RESIDENT=$r timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/r06k_bench_res$r.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06k_bench_res$r.json'))
+print('resident=$r:', d['ms_per_step'], d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06k_xsweep.txt
+    done
+    ;;
   r06i)   # resident cross-attention, second form (Q pipeline re-ordered, query blocks cut over workgroups when pairs are few): tests + sweep + step A/B
     PT="python -m pytest -q -m gpu --timeout=600"
     timeout 900 $PT tests/test_kernels_gpu.py -k "resident or test_attention" 2>&1 | tail -3 | tee gpurun_out/r06i_tests.txt

@@ -111,24 +111,41 @@ struct RowMax {            // 20 steps: four v_max3 chains, cross-half swap
 // ---- exp / row sum / bf16 pack of one 32-query block as a sequence of 80 single-instruction steps: 32 v_exp_f32,
 // 32 v_add_f32 (row sum of the unrounded probabilities), 16 v_cvt_pk_bf16_f32; each op trails the exponentials it
 // depends on by a round.  (Tried: v_dot2c_f32_bf16 on the packed pairs instead of the adds - 64 steps - no faster.)
-enum EsKind : int { ES_EX = 0, ES_AD = 1, ES_PK = 2 };
+// AM_A64_DOTSUM (round-6 probe of the lazy kernel, OFF: product ISA unchanged): the row sum over the bf16-ROUNDED probabilities - the
+// values the P.V MFMAs multiply - as ONE v_dot2c_f32_bf16 per packed pair (acc += p.lo * 1 + p.hi * 1) instead of two v_add_f32 on the
+// unrounded exponentials: 64 softmax steps per block instead of 80.  Measured on one box, three interleaved rounds
+// (profiles/r06m_dotsum_ab.txt): 26.92 ms against 25.60 (+5 %), 37.1 J per launch against 34.7, matrix pipe 0.63 busy against 0.75 - the
+// dot occupies the VALU port longer than the two adds it replaces, as v_pk_add_f32 did in round 5.  Fewer instructions is not fewer cycles.
+#ifndef AM_A64_DOTSUM
+#define AM_A64_DOTSUM 0
+#endif
+enum EsKind : int { ES_EX = 0, ES_AD = 1, ES_PK = 2, ES_DT = 3 };
 struct EsSeq { int n; int cost; int kind[80]; int arg[80]; };
-__device__ __host__ constexpr EsSeq es_make_seq() {
+__device__ __host__ constexpr EsSeq es_make_seq(bool dot = false) {
   EsSeq q{};
   int n = 0;
   auto put = [&](int k, int a) { q.kind[n] = k; q.arg[n] = a; ++n; };
   for (int r = 0; r < 16; ++r) {
     put(ES_EX, 2 * r);
     put(ES_EX, 2 * r + 1);
-    if (r >= 1) {
+    if (dot) {                       // the pack trails its exponentials by a round, the dot its pack by another
+      if (r >= 1) put(ES_PK, r - 1);
+      if (r >= 2) put(ES_DT, r - 2);
+    } else if (r >= 1) {
       put(ES_AD, 2 * r - 2);
       put(ES_AD, 2 * r - 1);
       put(ES_PK, r - 1);
     }
   }
-  put(ES_AD, 30);
-  put(ES_AD, 31);
-  put(ES_PK, 15);
+  if (dot) {
+    put(ES_PK, 15);
+    put(ES_DT, 14);
+    put(ES_DT, 15);
+  } else {
+    put(ES_AD, 30);
+    put(ES_AD, 31);
+    put(ES_PK, 15);
+  }
   q.n = n;
   // Issue-slot cost model for spreading the steps over a phase's MFMA gaps: a wave issues one instruction per 4 cycles
   // and v_exp_f32 holds the port for two slots (tools/ubench/mfma_fillers.hip), so a step costs 2 (exp) or 1.
@@ -179,9 +196,9 @@ __device__ __host__ constexpr EsTab32 es_make_tab32(const EsSeq& q, bool pv) {
   return t;
 }
 
-template <int ABL>
+template <int ABL, bool DOT = false>
 struct ExpSumPackT {
-  static constexpr EsSeq SEQ = es_make_seq();
+  static constexpr EsSeq SEQ = es_make_seq(DOT);
   float rs[4];
   __device__ __forceinline__ void init() { rs[0] = rs[1] = rs[2] = rs[3] = 0.f; }
   __device__ __forceinline__ static float get(const f32x16_t& sa, const f32x16_t& sb, int e) { return e < 16 ? sa[e] : sb[e - 16]; }
@@ -197,13 +214,26 @@ struct ExpSumPackT {
     PIN(v);
     w[pr >> 2][pr & 3] = v;
   }
+  // rs[pr & 3] += lo + hi of packed pair pr.  Inline asm (this hipcc cannot select the builtin), so its hazards are ours: a dot's result may
+  // feed the SrcC of the next dot of the same opcode back to back, but any OTHER VALU reading it needs 3 wait states - total() below.
+  __device__ __forceinline__ void dt(int pr, u32x4_t (&w)[4]) {
+#ifdef AM_F16
+    asm volatile("v_dot2c_f32_f16 %0, 0x3c003c00, %1" : "+v"(rs[pr & 3]) : "v"(w[pr >> 2][pr & 3]));
+#else
+    asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(rs[pr & 3]) : "v"(w[pr >> 2][pr & 3]));
+#endif
+  }
   __device__ __forceinline__ void step(int n, f32x16_t& sa, f32x16_t& sb, u32x4_t (&w)[4]) {
     const int k = SEQ.kind[n], a = SEQ.arg[n];
     if (k == ES_EX) ex(sa, sb, a);
     else if (k == ES_AD) ad(sa, sb, a);
+    else if (k == ES_DT) dt(a, w);
     else pk(sa, sb, a, w);
   }
-  __device__ __forceinline__ float total() const { return (rs[0] + rs[1]) + (rs[2] + rs[3]); }
+  __device__ __forceinline__ float total() {
+    if (DOT) asm volatile("s_nop 2" : "+v"(rs[0]), "+v"(rs[1]), "+v"(rs[2]), "+v"(rs[3]));
+    return (rs[0] + rs[1]) + (rs[2] + rs[3]);
+  }
 };
 
 // ABL (timing ablations, numerically meaningless, AM_ATTN_ABLATIONS builds only): 1 = no exp, 2 = no row max,
@@ -490,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
     const unsigned char* v_st = smem + ((g + 3) & 3) * STAGE_B;   // V^T(g-1)
     const unsigned char* k_st = smem + ((g + 1) & 3) * STAGE_B;   // K(g+1)
     const unsigned char* vn_st = smem + (g & 3) * STAGE_B;        // V^T(g), for the next iteration's first step
-    ExpSumPackT<ABL> es;
+    ExpSumPackT<ABL, AM_A64_DOTSUM != 0> es;
     constexpr EsTab32 ES1 = es_make_tab32(es.SEQ, true), ES2 = es_make_tab32(es.SEQ, false);
     auto bf = [](const u32x4_t& w) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8_t, w); };
     // ===== phase 1: O += V^T(g-1) P^T(g-1) || softmax of block 0; K(g+3) DMA; K(g+1) prefetch =====
@@ -783,7 +813,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(am_attn_args p, int 
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    float l = l_run[j] - (float)(cnt * p.nchunks) * __builtin_amdgcn_exp2f(-m_run[j]);
+    // (lazy kernel with AM_A64_DOTSUM: the row sums hold ROUNDED probabilities, a padded key's among them; its m_run is a whole number
+    // of octaves unless a resumed state says otherwise, so the rounding is the identity almost always)
+    const float p_pad = __builtin_amdgcn_exp2f(-m_run[j]);
+    float l = l_run[j] - (float)(cnt * p.nchunks) * ((LAZY && AM_A64_DOTSUM) ? rbf(p_pad) : p_pad);
     l += __shfl_xor(l, 32);
     // LAZY: m_run starts at tile 0's max (or at the saved state's) and only ever moves up by whole octaves when a row sum says so.
     // A row whose scores all sit far below it has lost its sum to underflow: let the exact kernel redo the workgroup.

@@ -308,5 +308,21 @@ print('resident=$r:', d['ms_per_step'], d['nominal']['ms_per_step'], d['with_exa
           # the product (free-running) kernel's timing ablations + the 8-wave form's, same box
     ACTIONMESH_AMD_LIB=$PWD/build/variants/libam_fp8prof.so python tools/kernel_bench.py --only attn --product-only --fp8 --ablate-fp8 --reps 3 2>&1 | grep -E "fp8|self-attn" | tee gpurun_out/r06j_fp8_ablations.txt
     ;;
+  r06m)   # row sums over the ROUNDED probabilities as v_dot2c_f32_bf16 (AM_A64_DOTSUM: 64 softmax steps per block instead of 80): distance to fp64
+          # of both builds, interleaved launch timings, joules, the attention tests on the candidate, same-box step A/B
+    V=$PWD/build/variants
+    for v in sum dot; do echo "=== $v"; ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_accuracy.py 2>/dev/null; done | tee gpurun_out/r06m_accuracy.txt
+    for round in 1 2 3; do for v in sum dot; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee gpurun_out/r06m_dotsum_ab.txt
+    ACTIONMESH_AMD_LIB=$V/libam_dot.so timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "attention" --timeout=300 2>&1 | tail -3 | tee gpurun_out/r06m_tests.txt
+    for v in sum dot sum dot; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06m_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06m_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06m_dotsum_ab.txt
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

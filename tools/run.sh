@@ -324,5 +324,60 @@ import json; d=json.load(open('gpurun_out/r06m_bench_$v.json')); r=d['roofline']
 print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06m_dotsum_ab.txt
     done
     ;;
+  r06n)   # this round's build under the firmware telemetry: the limiter probe (idle / N(0,1) / zero-operand legs: clock, power, PPT residency) and the
+          # energy table of the ablation build (VERDICT r05 next #5 names profiles/r06_energy_table.*); the MFMA-shape rows are r06d_mfma_energy.*
+    python tools/limiter_probe.py --seconds 2 --out gpurun_out/r06_limiter_probe.json 2>&1 | grep -v "^{" | tail -14 | tee gpurun_out/r06_limiter_probe.txt
+    ACTIONMESH_AMD_LIB=build/variants/libam_abl.so python tools/limiter_probe.py --energy-table --seconds 1.5 --out gpurun_out/r06_energy_table.json 2>&1 | grep -v "^{" | tail -24 | tee gpurun_out/r06_energy_table.txt
+    ;;
+  r06p)   # where a phase's four LDS-DMA pieces sit (AM_A64_DMAPOS: 0 = first four even gaps, 1 = one per k-step quarter, 2 = P.V gaps 4-7, 3 = two pairs):
+          # bit identity, interleaved launch timings, step A/B on one box
+    V=$PWD/build/variants
+    for v in dp0 dp1 dp2 dp3; do ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_bits.py 2>/dev/null > gpurun_out/r06p_bits_$v.txt; done
+    for v in dp1 dp2 dp3; do if cmp -s gpurun_out/r06p_bits_dp0.txt gpurun_out/r06p_bits_$v.txt; then echo "BIT-IDENTICAL: $v vs dp0"; else echo "DIFFERENT BITS: $v"; fi; done | tee gpurun_out/r06p_dmapos_ab.txt
+    for round in 1 2 3; do for v in dp0 dp1 dp2 dp3; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee -a gpurun_out/r06p_dmapos_ab.txt
+    for v in dp0 dp1 dp2 dp3; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06p_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06p_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06p_dmapos_ab.txt
+    done
+    ;;
+  r06q)   # v_exp_legacy_f32: rate / price beside MFMAs / accuracy (tools/ubench/exp_legacy.hip), then the 4x64 attention kernel with it
+          # (AM_A64_EXPLEGACY): distance to fp64, interleaved launch timings, step A/B
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/exp_legacy tools/ubench/exp_legacy.hip && /tmp/exp_legacy 2>&1 | tee gpurun_out/r06q_exp_legacy_ubench.txt
+    V=$PWD/build/variants
+    for v in el0 el1; do echo "=== $v"; ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_accuracy.py 2>/dev/null; done | tee gpurun_out/r06q_accuracy.txt
+    for round in 1 2 3; do for v in el0 el1; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee gpurun_out/r06q_explegacy_ab.txt
+    for v in el0 el1 el0 el1; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06q_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06q_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06q_explegacy_ab.txt
+    done
+    ;;
+  r06r)   # block 1's first M exponentials beside the P.V MFMAs of phase 1 (AM_A64_EARLYEX; AGPR-form MFMAs hide ~6 VALU slots, the VGPR-form QK^T ones ~2):
+          # bit identity, interleaved launch timings, step A/B on one box.  usage: tools/run.sh r06r "ee0 ee24 ee16 ..."
+    V=$PWD/build/variants
+    VARS=${1:-"ee0 ee24 ee16 ee24c0"}
+    FIRST=$(echo $VARS | cut -d" " -f1)
+    for v in $VARS; do ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_bits.py 2>/dev/null > gpurun_out/r06r_bits_$v.txt; done
+    for v in $VARS; do if cmp -s gpurun_out/r06r_bits_$FIRST.txt gpurun_out/r06r_bits_$v.txt; then echo "BIT-IDENTICAL: $v vs $FIRST"; else echo "DIFFERENT BITS: $v"; fi; done | tee gpurun_out/r06r_earlyex_ab.txt
+    for round in 1 2 3; do for v in $VARS; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee -a gpurun_out/r06r_earlyex_ab.txt
+    for v in $VARS; do
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-nominal 2>/dev/null | tail -1 > gpurun_out/r06r_bench_$v.json
+      python -c "
+import json; d=json.load(open('gpurun_out/r06r_bench_$v.json')); r=d['roofline']
+print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06r_earlyex_ab.txt
+    done
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

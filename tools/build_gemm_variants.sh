@@ -8,7 +8,7 @@ make -s all
 OUT=../../build/variants
 mkdir -p $OUT
 CXX="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize -I."
-OTHERS="am_elementwise.o am_attention.o am_attention64.o am_attention_fp8.o am_norm.o am_peer.o am_pointcloud.o am_model.o"
+OTHERS="am_elementwise.o am_attention.o am_attention64.o am_attention_fp8.o am_norm.o am_peer.o am_pointcloud.o am_model.o host/am_phase_loop.o"
 for spec in "$@"; do
   name="${spec%%=*}"; flags="${spec#*=}"; src=am_gemm.hip
   if [[ "$flags" == @* ]]; then src="${flags#@}"; flags=""; fi

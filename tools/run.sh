@@ -379,5 +379,19 @@ import json; d=json.load(open('gpurun_out/r06r_bench_$v.json')); r=d['roofline']
 print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j'), 'GHz', r.get('effective_clock_ghz'), 'busy', r.get('pipe_busy'), 'W', (r.get('clock_telemetry') or {}).get('average_power_w'), d['latents_fingerprint']['rms'])" | tee -a gpurun_out/r06r_earlyex_ab.txt
     done
     ;;
+  r06s)   # cache-policy bits on the operand LDS-DMA loads (default / nt / sc1 / sc0 sc1 / sc1 nt): attention K / V^T streams (AM_A64_DMA_CPOL) and the
+          # ping-pong GEMM's A / W stages (AM_G_AUX_A / _W), interleaved rounds on one box; bits must not change
+    V=$PWD/build/variants
+    for v in cp0 cp1 cp2 cp3 cp4; do ACTIONMESH_AMD_LIB=$V/libam_$v.so python tools/diag/attn_bits.py 2>/dev/null > gpurun_out/r06s_bits_$v.txt; done
+    for v in cp1 cp2 cp3 cp4; do if cmp -s gpurun_out/r06s_bits_cp0.txt gpurun_out/r06s_bits_$v.txt; then echo "BIT-IDENTICAL: $v vs cp0"; else echo "DIFFERENT BITS: $v"; fi; done | tee gpurun_out/r06s_cpol_ab.txt
+    for round in 1 2; do for v in cp0 cp1 cp2 cp3 cp4; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only attn --product-only --reps 6 2>&1 | grep "self-attn"
+    done; done | tee -a gpurun_out/r06s_cpol_ab.txt
+    for round in 1 2; do for v in g00 g22 g20 g02 gss gsn; do
+      echo "=== round $round $v"
+      ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only gemm --product-only --reps 20 2>&1 | grep "256sq-pingpong:"
+    done; done | tee gpurun_out/r06s_gemm_cpol_ab.txt
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac

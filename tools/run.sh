@@ -393,5 +393,18 @@ print('$v:', d['ms_per_step'], r['launch_ms'], r['frac'], 'J', r.get('energy_j')
       ACTIONMESH_AMD_LIB=$V/libam_$v.so timeout 300 python tools/kernel_bench.py --only gemm --product-only --reps 20 2>&1 | grep "256sq-pingpong:"
     done; done | tee gpurun_out/r06s_gemm_cpol_ab.txt
     ;;
+  r06t)   # after the final run, on another box: the driver's own bench command (roofline.traffic now resolved from the committed record of this sha) and a
+          # kernel trace of the NOMINAL step on the final sources (r06d's predates the resident cross-attention kernel)
+    export TMPDIR=/tmp
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r06t_bench_driver_style.json
+    python -c "
+import json; d=json.load(open('gpurun_out/r06t_bench_driver_style.json')); r=d['roofline']
+print({k: d[k] for k in ('value','ms_per_step','steps','warmup','step_frac_of_bf16_peak')}, r['launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r.get('energy_j'), d['nominal']['ms_per_step'], d['with_exact_shortcuts']['ms_per_step'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+print('non-attention ms per step', round(d['ms_per_step'] - 21 * r['launch_ms'], 2))"
+    OUT=$PWD/gpurun_out/prof_r06t_nominal; rm -rf $OUT; mkdir -p $OUT
+    timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python bench.py --shape nominal --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1
+    python tools/summarize_prof.py $OUT gpurun_out/r06t_nominal 2>&1 | tail -3
+    head -16 gpurun_out/r06t_nominal_by_launch_shape.csv | cut -c1-200
+    ;;
   *) echo "unknown entry $NAME"; exit 2 ;;
 esac
